@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Benchmark of the brute-force matching hot path on MI355X.
+
+A step = one pass of the hot path over one image pair of the headline
+configuration (8192 x 8192 descriptors of 128 floats, ratio 0.8, cross-check):
+distance/top-k kernel, exact re-rank, cross-check, compaction, copy of the
+compact match list to pinned host memory.  Descriptors are resident in HBM
+before the timed region starts.  With --gpus N every rank matches its own
+pairs (pairs are independent: no collective on the data path), so the value is
+the sum over ranks ("weak" scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FEATURES = 8192
+PLANTED = 4096
+PEAK_FP32_MFMA_TFLOPS = 157.3  # 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def cpu_baseline(A, B, expected):
+    """Time the CPU oracle (a port of the reference matcher) on this host.
+
+    Sample: one full 8192x8192 pair with cross-check on two threads, which is
+    how the reference runs a pair (its ThreadPool has two workers, one per
+    direction); then the same pair on 16 threads.
+    """
+    from oracle import oracle
+    t0 = time.perf_counter()
+    l, r, d = oracle.match_pair(A, B, 0.8, True, threads=2)
+    t2 = time.perf_counter() - t0
+    same = (l.tolist() == expected[0].tolist() and r.tolist() == expected[1].tolist())
+    t0 = time.perf_counter()
+    oracle.match_pair(A, B, 0.8, True, threads=16)
+    t16 = time.perf_counter() - t0
+    return {"value": 1.0 / t2, "unit": "pairs/s", "cores": 2, "kind": "port",
+            "sample": "one full 8192x8192 pair, ratio 0.8 + cross-check, 2 threads (the reference's pool size)",
+            "seconds_per_pair": t2, "matches_equal_gpu": bool(same),
+            "all_cores": {"value": 1.0 / t16, "cores": 16, "seconds_per_pair": t16}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-events", action="store_true",
+                    help="do not bracket the distance kernel with HIP events in the timed region")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    import sfm_amd
+    from sfm_amd import synth
+
+    m = sfm_amd.Matcher(local_rank if dist_on else 0)
+    A, B, truth = synth.make_pair(N_FEATURES, N_FEATURES, PLANTED, seed=2024 + rank)
+    t0 = time.perf_counter()
+    m.upload(0, A)
+    m.upload(1, B)
+    upload_s = time.perf_counter() - t0
+    pairs = np.array([[0, 1]], np.int64)
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+    m.sync()
+    m.reset_stats()
+    m.set_profiling(not args.no_profile_events)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+    m.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = m.stats()
+    m.set_profiling(False)
+    cnt = int(out[0][0])
+    got = (out[1][0, :cnt].astype(np.int64), out[2][0, :cnt].astype(np.int64))
+
+    if dist_on:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total_pairs = args.steps * world
+        value = total_pairs / elapsed
+        flop_per_launch = 2.0 * N_FEATURES * N_FEATURES * 128
+        roof = None
+        if st["distance_launches"]:
+            avg_ms = st["distance_ms"] / st["distance_launches"]
+            achieved = st["distance_flop"] / st["distance_launches"] / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "kernel": "k_distance_topk", "avg_launch_ms": avg_ms, "flop_per_launch": flop_per_launch}
+        planted_found = len(set(zip(got[0].tolist(), got[1].tolist())) & set(map(tuple, truth.tolist())))
+        line = {
+            "metric": "image pairs/sec, 8k x 8k 128-d descriptors",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "single synthetic pair, 8192x8192 128-d float descriptors, "
+                                   "ratio 0.8 + cross-check (BASELINE.json configs[1])",
+                       "pairs_per_step_per_gpu": 1, "planted_matches": PLANTED, "matches_found": cnt,
+                       "planted_found": planted_found, "parallelism": "pairs sharded over ranks, no collective"},
+            "frac_of_fp32_mfma_peak_end_to_end": value / world * flop_per_launch / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "rescanned_queries_per_pair": st["rescanned_queries"] / max(1, st["pairs"]),
+            "upload_seconds_both_images": upload_s,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(A, B, got)
+        print(json.dumps(line), flush=True)
+
+    m.close()
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+"""ctypes binding of include/sfm_hip.h."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libsfm_hip.so")
+
+EXPORTS = (
+    "sfm_hip_device_count", "sfm_hip_ctx_create", "sfm_hip_ctx_destroy", "sfm_hip_last_error",
+    "sfm_hip_upload_image", "sfm_hip_drop_image", "sfm_hip_drop_all_images", "sfm_hip_image_size",
+    "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
+    "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats",
+)
+
+
+class SfmHipError(RuntimeError):
+    pass
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("pairs", ctypes.c_uint64), ("queries", ctypes.c_uint64), ("rescanned_queries", ctypes.c_uint64),
+                ("distance_launches", ctypes.c_uint64), ("distance_ms", ctypes.c_double),
+                ("distance_flop", ctypes.c_double)]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def library():
+    """Load libsfm_hip.so.  Raises if it has not been built: there is no other path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise SfmHipError("%s is missing: run `python -m sfm_amd.build` (needs hipcc)" % _LIB_PATH)
+    # When torch is part of the process its bundled HIP runtime must be the one
+    # both sides use; importing it first makes the loader bind ours to it.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    lib.sfm_hip_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    lib.sfm_hip_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    lib.sfm_hip_ctx_destroy.argtypes = [vp]
+    lib.sfm_hip_ctx_destroy.restype = None
+    lib.sfm_hip_last_error.argtypes = [vp]
+    lib.sfm_hip_last_error.restype = ctypes.c_char_p
+    lib.sfm_hip_upload_image.argtypes = [vp, i64, vp, i32]
+    lib.sfm_hip_drop_image.argtypes = [vp, i64]
+    lib.sfm_hip_drop_all_images.argtypes = [vp]
+    lib.sfm_hip_image_size.argtypes = [vp, i64, ctypes.POINTER(i32)]
+    lib.sfm_hip_match_pairs.argtypes = [vp, vp, i32, ctypes.c_double, ctypes.c_int, vp, vp, vp, vp, i64]
+    lib.sfm_hip_sync.argtypes = [vp]
+    lib.sfm_hip_host_alloc.argtypes = [ctypes.c_size_t]
+    lib.sfm_hip_host_alloc.restype = vp
+    lib.sfm_hip_host_free.argtypes = [vp]
+    lib.sfm_hip_host_free.restype = None
+    lib.sfm_hip_set_profiling.argtypes = [vp, ctypes.c_int]
+    lib.sfm_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    lib.sfm_hip_reset_stats.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+class _Pinned:
+    """A pinned host array owned by the library's allocator."""
+
+    def __init__(self, lib, shape, dtype):
+        self._lib = lib
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib.sfm_hip_host_alloc(max(n, 1))
+        if not self.ptr:
+            raise SfmHipError("pinned allocation of %d bytes failed" % n)
+        buf = (ctypes.c_char * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self._lib.sfm_hip_host_free(self.ptr)
+            self.ptr = None
+
+
+class Matcher:
+    """One context on one GPU.  Mirrors the C ABI one to one."""
+
+    def __init__(self, device=0):
+        self._lib = library()
+        h = ctypes.c_void_p()
+        rc = self._lib.sfm_hip_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise SfmHipError("sfm_hip_ctx_create(%d) failed (%d): %s"
+                              % (device, rc, self._lib.sfm_hip_last_error(None).decode()))
+        self._h = h
+        self._bufs = None
+        self._bufs_shape = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self._bufs:
+                for b in self._bufs:
+                    b.free()
+                self._bufs = None
+            self._lib.sfm_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SfmHipError("%s failed (%d): %s" % (what, rc, self._lib.sfm_hip_last_error(self._h).decode()))
+
+    def upload(self, image_id, descriptors):
+        d = np.ascontiguousarray(descriptors, dtype=np.float32)
+        if d.ndim != 2 or d.shape[1] != 128:
+            raise ValueError("descriptors must be [n, 128]")
+        self._check(self._lib.sfm_hip_upload_image(self._h, int(image_id), d.ctypes.data, d.shape[0]),
+                    "sfm_hip_upload_image")
+
+    def drop(self, image_id):
+        self._check(self._lib.sfm_hip_drop_image(self._h, int(image_id)), "sfm_hip_drop_image")
+
+    def drop_all(self):
+        self._check(self._lib.sfm_hip_drop_all_images(self._h), "sfm_hip_drop_all_images")
+
+    def image_size(self, image_id):
+        n = ctypes.c_int32()
+        self._check(self._lib.sfm_hip_image_size(self._h, int(image_id), ctypes.byref(n)), "sfm_hip_image_size")
+        return n.value
+
+    def _outputs(self, n_pairs, stride):
+        shape = (n_pairs, stride)
+        if self._bufs is None or self._bufs_shape != shape:
+            if self._bufs:
+                for b in self._bufs:
+                    b.free()
+            self._bufs = [_Pinned(self._lib, (n_pairs,), np.int32), _Pinned(self._lib, shape, np.int32),
+                          _Pinned(self._lib, shape, np.int32), _Pinned(self._lib, shape, np.float32)]
+            self._bufs_shape = shape
+        return self._bufs
+
+    def match_pairs_async(self, pairs, ratio=0.8, cross_check=True, stride=None):
+        """Queue the pairs; returns the pinned output arrays (valid after sync())."""
+        p = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+        if stride is None:
+            stride = max([self.image_size(i) for i in set(p[:, 0].tolist())] + [1])
+        cnt, lhs, rhs, dist = self._outputs(p.shape[0], int(stride))
+        self._check(self._lib.sfm_hip_match_pairs(self._h, p.ctypes.data, p.shape[0], float(ratio),
+                                                  int(bool(cross_check)), cnt.ptr, lhs.ptr, rhs.ptr, dist.ptr,
+                                                  int(stride)), "sfm_hip_match_pairs")
+        return cnt.array, lhs.array, rhs.array, dist.array
+
+    def sync(self):
+        self._check(self._lib.sfm_hip_sync(self._h), "sfm_hip_sync")
+
+    def match_pairs(self, pairs, ratio=0.8, cross_check=True):
+        """[(lhs_idx int64, rhs_idx int64, dist float32)] per pair, as the reference stores them."""
+        cnt, lhs, rhs, dist = self.match_pairs_async(pairs, ratio, cross_check)
+        self.sync()
+        out = []
+        for k in range(cnt.shape[0]):
+            c = int(cnt[k])
+            out.append((lhs[k, :c].astype(np.int64), rhs[k, :c].astype(np.int64), dist[k, :c].copy()))
+        return out
+
+    def set_profiling(self, on):
+        self._check(self._lib.sfm_hip_set_profiling(self._h, int(bool(on))), "sfm_hip_set_profiling")
+
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.sfm_hip_get_stats(self._h, ctypes.byref(s)), "sfm_hip_get_stats")
+        return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def reset_stats(self):
+        self._check(self._lib.sfm_hip_reset_stats(self._h), "sfm_hip_reset_stats")

@@ -1,0 +1,76 @@
+"""Compile the gfx950 shared library (and the C++ host programs) in-tree.
+
+hipcc cross-compiles without a GPU.  Outputs land in sfm_amd/lib/ and are
+git-ignored; they travel to the GPU machine with the source tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sfm_amd", "csrc")
+HOST = os.path.join(ROOT, "sfm_amd", "host")
+LIBDIR = os.path.join(ROOT, "sfm_amd", "lib")
+LIB = os.path.join(LIBDIR, "libsfm_hip.so")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build step failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def build_library(force=False):
+    """libsfm_hip.so: HIP kernels + C ABI (include/sfm_hip.h)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in ("sfm_hip_capi.hip", "bf_kernels.hpp")]
+    srcs.append(os.path.join(ROOT, "include", "sfm_hip.h"))
+    if force or _newer(LIB, srcs):
+        _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", LIB, srcs[0]])
+    return LIB
+
+
+def build_host(force=False):
+    """C++ host layer: the matcher class behind the reference's interface, the
+    driver program and the host-side test programs.  Returns {name: path}."""
+    out = {}
+    if not os.path.isdir(HOST):
+        return out
+    build_library()
+    common = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith((".hpp", ".cc"))]
+    inc = ["-I", HOST, "-I", os.path.join(ROOT, "include")]
+    link = ["-L", LIBDIR, "-lsfm_hip", "-Wl,-rpath," + LIBDIR, "-pthread"]
+    lib_srcs = [os.path.join(HOST, f) for f in ("hip_brute_force_matcher.cc", "exhaustive_pair_builder.cc", "sfm_data_io.cc")
+                if os.path.exists(os.path.join(HOST, f))]
+    for name in ("feature_match_main",):
+        src = os.path.join(HOST, name + ".cc")
+        if not os.path.exists(src):
+            continue
+        exe = os.path.join(LIBDIR, name)
+        if force or _newer(exe, common + [LIB]):
+            _run(["g++", "-O2", "-std=c++17"] + inc + ["-o", exe, src] + lib_srcs + link)
+        out[name] = exe
+    return out
+
+
+def build_all(force=False):
+    build_library(force)
+    return build_host(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print(LIB)

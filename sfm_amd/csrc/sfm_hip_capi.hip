@@ -1,0 +1,560 @@
+// Host side of the C ABI declared in include/sfm_hip.h: context, image store,
+// work-space management, batching of pairs into launches, result copies.
+#include "../../include/sfm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "bf_kernels.hpp"
+
+using namespace sfm;
+
+namespace {
+
+thread_local std::string g_last_error;  // failures without a context
+
+struct Image {
+  float* d = nullptr;    // [n_pad][128]
+  float* norms = nullptr;  // [n_pad + 1]
+  int32_t n = 0, n_pad = 0;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct TimedLaunch {
+  hipEvent_t start, stop;
+  double flop;
+};
+
+}  // namespace
+
+struct sfm_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::map<int64_t, Image> images;
+  std::string last_error;
+
+  // grow-only device work space
+  DevBuf pairs_dev, blocks_dev, rowpart, colpart, best, queue, qcount, out_dev;
+  // pinned staging for the per-batch tables, two slots
+  void* stage_host[2] = {nullptr, nullptr};
+  size_t stage_bytes[2] = {0, 0};
+  hipEvent_t stage_free[2] = {nullptr, nullptr};
+  int stage_slot = 0;
+  // pinned landing zone for per-batch rescan counts
+  uint32_t* qcount_host = nullptr;
+  size_t qcount_host_cap = 0, qcount_host_used = 0;
+
+  bool profiling = false;
+  std::vector<TimedLaunch> timed;
+  std::vector<hipEvent_t> event_pool;
+  sfm_hip_stats stats{};
+
+  size_t batch_bytes_limit = (size_t)6 << 30;  // work space per batch
+  int max_pairs_per_batch = 256;
+};
+
+namespace {
+
+int fail(sfm_hip_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->last_error = msg; else g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                 \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? SFM_HIP_ERR_NOMEM : SFM_HIP_ERR_HIP,    \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+    }                                                                                      \
+  } while (0)
+
+int ensure(sfm_hip_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return SFM_HIP_OK;
+  // the old buffer may still be in use by queued work
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (b.p) HIP_TRY(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  size_t want = bytes + bytes / 4;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    want = bytes;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+  }
+  b.bytes = want;
+  return SFM_HIP_OK;
+}
+
+int ensure_stage(sfm_hip_ctx* ctx, int slot, size_t bytes) {
+  if (ctx->stage_bytes[slot] >= bytes) return SFM_HIP_OK;
+  if (ctx->stage_host[slot]) HIP_TRY(ctx, hipHostFree(ctx->stage_host[slot]));
+  ctx->stage_host[slot] = nullptr;
+  ctx->stage_bytes[slot] = 0;
+  HIP_TRY(ctx, hipHostMalloc(&ctx->stage_host[slot], bytes * 2, hipHostMallocDefault));
+  ctx->stage_bytes[slot] = bytes * 2;
+  return SFM_HIP_OK;
+}
+
+void free_image(Image& im) {
+  if (im.d) (void)hipFree(im.d);
+  if (im.norms) (void)hipFree(im.norms);
+  im = Image();
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PairPlan {
+  const Image* X;
+  const Image* Y;
+  int nchunks, chunk_cols;
+  size_t rowpart_words, colpart_words, best_words;
+  size_t bytes() const { return (rowpart_words + colpart_words + best_words) * 4; }
+};
+
+// Split the columns of a pair into chunks so that a batch has enough workgroups
+// to fill the chip (two per CU); fewer chunks mean fewer partial lists.
+void plan_chunks(PairPlan& pl, int row_blocks_in_batch_estimate) {
+  const int nb_pad = pl.Y->n_pad;
+  const int target_blocks = 512;
+  int want = (target_blocks + row_blocks_in_batch_estimate - 1) / std::max(1, row_blocks_in_batch_estimate);
+  want = std::max(1, std::min(want, nb_pad / SN));
+  int cols = (int)align_up((size_t)(nb_pad + want - 1) / want, SN);
+  cols = std::min(cols, MAX_CHUNK_COLS);
+  pl.chunk_cols = cols;
+  pl.nchunks = (nb_pad + cols - 1) / cols;
+  pl.rowpart_words = (size_t)pl.nchunks * ROWPART_FIELDS * pl.X->n_pad;
+  pl.colpart_words = (size_t)(pl.X->n_pad / BM) * 3 * nb_pad;
+  pl.best_words = 2 * (size_t)pl.X->n_pad + 2 * (size_t)nb_pad;
+}
+
+hipEvent_t get_event(sfm_hip_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+int fold_timed(sfm_hip_ctx* ctx) {
+  for (auto& t : ctx->timed) {
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, t.start, t.stop));
+    ctx->stats.distance_ms += ms;
+    ctx->stats.distance_flop += t.flop;
+    ctx->stats.distance_launches += 1;
+    ctx->event_pool.push_back(t.start);
+    ctx->event_pool.push_back(t.stop);
+  }
+  ctx->timed.clear();
+  return SFM_HIP_OK;
+}
+
+int fold_qcounts(sfm_hip_ctx* ctx) {
+  for (size_t i = 0; i < ctx->qcount_host_used; i++) ctx->stats.rescanned_queries += ctx->qcount_host[i];
+  ctx->qcount_host_used = 0;
+  return SFM_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfm_hip_device_count(int* count) {
+  if (!count) return fail(nullptr, SFM_HIP_ERR_INVALID, "count is null");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(nullptr, SFM_HIP_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
+  if (!out_ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "out_ctx is null");
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, SFM_HIP_ERR_HIP,
+                std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+  if (device < 0 || device >= n) return fail(nullptr, SFM_HIP_ERR_INVALID, "device ordinal out of range");
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(nullptr, SFM_HIP_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(nullptr, SFM_HIP_ERR_HIP,
+                std::string("device is ") + prop.gcnArchName + "; this library holds gfx950 code only");
+  sfm_hip_ctx* ctx = new sfm_hip_ctx();
+  ctx->device = device;
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&ctx->stage_free[s], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    std::string msg = std::string("context set-up: ") + hipGetErrorString(e);
+    delete ctx;
+    return fail(nullptr, SFM_HIP_ERR_HIP, msg);
+  }
+  *out_ctx = ctx;
+  return SFM_HIP_OK;
+}
+
+void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->images) free_image(kv.second);
+  for (DevBuf* b : {&ctx->pairs_dev, &ctx->blocks_dev, &ctx->rowpart, &ctx->colpart, &ctx->best, &ctx->queue,
+                    &ctx->qcount, &ctx->out_dev})
+    if (b->p) (void)hipFree(b->p);
+  for (int s = 0; s < 2; s++) {
+    if (ctx->stage_host[s]) (void)hipHostFree(ctx->stage_host[s]);
+    if (ctx->stage_free[s]) (void)hipEventDestroy(ctx->stage_free[s]);
+  }
+  if (ctx->qcount_host) (void)hipHostFree(ctx->qcount_host);
+  for (auto& t : ctx->timed) {
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* sfm_hip_last_error(const sfm_hip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (n < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative descriptor count");
+  if (n > 0 && !descriptors) return fail(ctx, SFM_HIP_ERR_INVALID, "descriptors is null");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // queued work may still read the image being replaced
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  auto it = ctx->images.find(image_id);
+  if (it != ctx->images.end()) {
+    free_image(it->second);
+    ctx->images.erase(it);
+  }
+  Image im;
+  im.n = n;
+  im.n_pad = (int32_t)align_up((size_t)std::max(n, 1), IMG_PAD);
+  const size_t row_bytes = DIM * sizeof(float);
+  HIP_TRY(ctx, hipMalloc((void**)&im.d, (size_t)im.n_pad * row_bytes));
+  hipError_t e = hipMalloc((void**)&im.norms, ((size_t)im.n_pad + 1) * sizeof(float));
+  if (e != hipSuccess) {
+    free_image(im);
+    return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc norms: ") + hipGetErrorString(e));
+  }
+  e = hipSuccess;
+  if (n > 0) e = hipMemcpyAsync(im.d, descriptors, (size_t)n * row_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && im.n_pad > n)
+    e = hipMemsetAsync(im.d + (size_t)n * DIM, 0, (size_t)(im.n_pad - n) * row_bytes, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(im.norms + im.n_pad, 0, sizeof(float), ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_norms, dim3((im.n_pad + 3) / 4), dim3(256), 0, ctx->stream, im.d, im.norms, n, im.n_pad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    free_image(im);
+    return fail(ctx, SFM_HIP_ERR_HIP, std::string("image upload: ") + hipGetErrorString(e));
+  }
+  ctx->images[image_id] = im;
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_drop_image(sfm_hip_ctx* ctx, int64_t image_id) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  auto it = ctx->images.find(image_id);
+  if (it == ctx->images.end()) return fail(ctx, SFM_HIP_ERR_INVALID, "unknown image id " + std::to_string(image_id));
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_image(it->second);
+  ctx->images.erase(it);
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_drop_all_images(sfm_hip_ctx* ctx) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& kv : ctx->images) free_image(kv.second);
+  ctx->images.clear();
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_image_size(sfm_hip_ctx* ctx, int64_t image_id, int32_t* n) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (!n) return fail(ctx, SFM_HIP_ERR_INVALID, "n is null");
+  auto it = ctx->images.find(image_id);
+  if (it == ctx->images.end()) return fail(ctx, SFM_HIP_ERR_INVALID, "unknown image id " + std::to_string(image_id));
+  *n = it->second.n;
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pairs, double ratio, int cross_check,
+                        int32_t* out_counts, int32_t* out_lhs_idx, int32_t* out_rhs_idx, float* out_dist,
+                        int64_t out_stride) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (n_pairs < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative pair count");
+  if (n_pairs == 0) return SFM_HIP_OK;
+  if (!pair_ids || !out_counts || !out_lhs_idx || !out_rhs_idx)
+    return fail(ctx, SFM_HIP_ERR_INVALID, "null pair list or output buffer");
+  if (out_stride < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative out_stride");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  // validate everything before queuing anything
+  std::vector<PairPlan> plans((size_t)n_pairs);
+  for (int p = 0; p < n_pairs; p++) {
+    auto ix = ctx->images.find(pair_ids[2 * p]);
+    auto iy = ctx->images.find(pair_ids[2 * p + 1]);
+    if (ix == ctx->images.end() || iy == ctx->images.end())
+      return fail(ctx, SFM_HIP_ERR_INVALID,
+                  "pair " + std::to_string(p) + " names an image that was not uploaded (" +
+                      std::to_string(pair_ids[2 * p]) + ", " + std::to_string(pair_ids[2 * p + 1]) + ")");
+    if (ix->second.n > out_stride)
+      return fail(ctx, SFM_HIP_ERR_INVALID, "out_stride smaller than the first image of pair " + std::to_string(p));
+    plans[p].X = &ix->second;
+    plans[p].Y = &iy->second;
+  }
+
+  int done = 0;
+  while (done < n_pairs) {
+    // ---- choose the batch: as many pairs as fit the work-space budget
+    int remaining = n_pairs - done;
+    long est_row_blocks = 0;
+    for (int p = done; p < done + std::min(remaining, ctx->max_pairs_per_batch); p++)
+      est_row_blocks += plans[p].X->n_pad / BM;
+    int count = 0;
+    size_t bytes = 0;
+    while (count < remaining && count < ctx->max_pairs_per_batch) {
+      PairPlan& pl = plans[done + count];
+      plan_chunks(pl, (int)std::min<long>(est_row_blocks, 1 << 20));
+      if (count > 0 && bytes + pl.bytes() > ctx->batch_bytes_limit) break;
+      bytes += pl.bytes();
+      count++;
+    }
+
+    // ---- lay out the work space and build the tables
+    size_t rowpart_words = 0, colpart_words = 0, best_words = 0, n_blocks = 0, n_queries = 0;
+    int max_na = 0, max_nb = 0;
+    for (int k = 0; k < count; k++) {
+      const PairPlan& pl = plans[done + k];
+      rowpart_words += pl.rowpart_words;
+      colpart_words += pl.colpart_words;
+      best_words += pl.best_words;
+      if (pl.X->n > 0 && pl.Y->n > 0) n_blocks += (size_t)(pl.X->n_pad / BM) * pl.nchunks;
+      n_queries += (size_t)pl.X->n + pl.Y->n;
+      max_na = std::max(max_na, pl.X->n);
+      max_nb = std::max(max_nb, pl.Y->n);
+    }
+    int rc;
+    if ((rc = ensure(ctx, ctx->pairs_dev, sizeof(PairDev) * count))) return rc;
+    if ((rc = ensure(ctx, ctx->blocks_dev, sizeof(BlockDev) * std::max<size_t>(n_blocks, 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->rowpart, rowpart_words * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->colpart, colpart_words * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->best, best_words * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->queue, sizeof(QueueEntry) * std::max<size_t>(n_queries, 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->qcount, 256))) return rc;
+    const size_t out_words = (size_t)count * (size_t)out_stride;
+    // counts | lhs | rhs | dist
+    if ((rc = ensure(ctx, ctx->out_dev, align_up((size_t)count * 4, 256) + 3 * align_up(out_words * 4, 256) + 256)))
+      return rc;
+
+    const size_t table_bytes = align_up(sizeof(PairDev) * count, 256) + sizeof(BlockDev) * n_blocks;
+    const int slot = ctx->stage_slot;
+    ctx->stage_slot ^= 1;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->stage_free[slot]));
+    if ((rc = ensure_stage(ctx, slot, table_bytes))) return rc;
+    PairDev* hp = reinterpret_cast<PairDev*>(ctx->stage_host[slot]);
+    BlockDev* hb = reinterpret_cast<BlockDev*>((char*)ctx->stage_host[slot] + align_up(sizeof(PairDev) * count, 256));
+
+    uint32_t* rp = (uint32_t*)ctx->rowpart.p;
+    uint32_t* cp = (uint32_t*)ctx->colpart.p;
+    uint32_t* bp = (uint32_t*)ctx->best.p;
+    size_t nb_i = 0;
+    double flop = 0.0;
+    for (int k = 0; k < count; k++) {
+      const PairPlan& pl = plans[done + k];
+      PairDev& d = hp[k];
+      d.x = pl.X->d;
+      d.xn = pl.X->norms;
+      d.y = pl.Y->d;
+      d.yn = pl.Y->norms;
+      d.rowpart = rp;
+      rp += pl.rowpart_words;
+      d.colpart = cp;
+      cp += pl.colpart_words;
+      d.fwd_best = (int32_t*)bp;
+      d.fwd_dist = (float*)(bp + pl.X->n_pad);
+      d.rev_best = (int32_t*)(bp + 2 * (size_t)pl.X->n_pad);
+      d.rev_dist = (float*)(bp + 2 * (size_t)pl.X->n_pad + pl.Y->n_pad);
+      bp += pl.best_words;
+      d.na = pl.X->n;
+      d.nb = pl.Y->n;
+      d.na_pad = pl.X->n_pad;
+      d.nb_pad = pl.Y->n_pad;
+      d.nchunks = pl.nchunks;
+      d.chunk_cols = pl.chunk_cols;
+      d.out_slot = k;
+      d.pad_ = 0;
+      if (pl.X->n > 0 && pl.Y->n > 0) {
+        // chunk-major: workgroups that run together stream the same columns
+        for (int c = 0; c < pl.nchunks; c++) {
+          const int col0 = c * pl.chunk_cols;
+          const int ncols = std::min(pl.chunk_cols, pl.Y->n_pad - col0);
+          for (int rb = 0; rb < pl.X->n_pad / BM; rb++) {
+            BlockDev& b = hb[nb_i++];
+            b.pair = k;
+            b.row0 = rb * BM;
+            b.col0 = col0;
+            b.ncols = ncols;
+            b.chunk = c;
+            b.pad_[0] = b.pad_[1] = b.pad_[2] = 0;
+          }
+        }
+        flop += 2.0 * pl.X->n * (double)pl.Y->n * DIM;
+      }
+    }
+
+    // ---- queue the batch
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pairs_dev.p, hp, sizeof(PairDev) * count, hipMemcpyHostToDevice, st));
+    if (n_blocks)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->blocks_dev.p, hb, sizeof(BlockDev) * n_blocks, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->stage_free[slot], st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->qcount.p, 0, 256, st));
+
+    const PairDev* dp = (const PairDev*)ctx->pairs_dev.p;
+    if (n_blocks) {
+      TimedLaunch tl{};
+      if (ctx->profiling) {
+        tl.start = get_event(ctx);
+        tl.stop = get_event(ctx);
+        tl.flop = flop;
+        HIP_TRY(ctx, hipEventRecord(tl.start, st));
+      }
+      hipLaunchKernelGGL(k_distance_topk, dim3((unsigned)n_blocks), dim3(256), 0, st, dp,
+                         (const BlockDev*)ctx->blocks_dev.p);
+      HIP_TRY(ctx, hipGetLastError());
+      if (ctx->profiling) {
+        HIP_TRY(ctx, hipEventRecord(tl.stop, st));
+        ctx->timed.push_back(tl);
+      }
+    }
+    QueueEntry* qu = (QueueEntry*)ctx->queue.p;
+    uint32_t* qc = (uint32_t*)ctx->qcount.p;
+    // Pairs with an empty image still go through the re-rank step: with no
+    // candidates every query comes out unmatched, as in the reference.  Their
+    // partial lists were never written, so give them empty ones.
+    for (int k = 0; k < count; k++) {
+      const PairPlan& pl = plans[done + k];
+      if (pl.X->n > 0 && pl.Y->n > 0) continue;
+      HIP_TRY(ctx, hipMemsetAsync(hp[k].rowpart, 0xFF, pl.rowpart_words * 4, st));
+      HIP_TRY(ctx, hipMemsetAsync(hp[k].colpart, 0xFF, pl.colpart_words * 4, st));
+    }
+    if (max_na > 0) {
+      hipLaunchKernelGGL(k_rerank<0>, dim3((max_na + 63) / 64, count), dim3(256), 0, st, dp, ratio, qu, qc);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    if (cross_check && max_nb > 0) {
+      hipLaunchKernelGGL(k_rerank<1>, dim3((max_nb + 63) / 64, count), dim3(256), 0, st, dp, ratio, qu, qc);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_rescan, dim3(512), dim3(256), 0, st, dp, ratio, (const QueueEntry*)qu, (const uint32_t*)qc);
+    HIP_TRY(ctx, hipGetLastError());
+
+    char* ob = (char*)ctx->out_dev.p;
+    int32_t* d_counts = (int32_t*)ob;
+    ob += align_up((size_t)count * 4, 256);
+    int32_t* d_lhs = (int32_t*)ob;
+    ob += align_up(out_words * 4, 256);
+    int32_t* d_rhs = (int32_t*)ob;
+    ob += align_up(out_words * 4, 256);
+    float* d_dist = (float*)ob;
+    hipLaunchKernelGGL(k_cross_compact, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, d_counts, d_lhs,
+                       d_rhs, d_dist, out_stride);
+    HIP_TRY(ctx, hipGetLastError());
+
+    const size_t o = (size_t)done * (size_t)out_stride;
+    HIP_TRY(ctx, hipMemcpyAsync(out_counts + done, d_counts, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+    if (out_words) {
+      HIP_TRY(ctx, hipMemcpyAsync(out_lhs_idx + o, d_lhs, out_words * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipMemcpyAsync(out_rhs_idx + o, d_rhs, out_words * 4, hipMemcpyDeviceToHost, st));
+      if (out_dist) HIP_TRY(ctx, hipMemcpyAsync(out_dist + o, d_dist, out_words * 4, hipMemcpyDeviceToHost, st));
+    }
+    // rescan count of this batch, folded into the statistics at the next sync
+    if (ctx->qcount_host_used == ctx->qcount_host_cap) {
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      fold_qcounts(ctx);
+      if (!ctx->qcount_host) {
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->qcount_host, 4096 * sizeof(uint32_t), hipHostMallocDefault));
+        ctx->qcount_host_cap = 4096;
+      }
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->qcount_host + ctx->qcount_host_used++, qc, 4, hipMemcpyDeviceToHost, st));
+
+    ctx->stats.pairs += (uint64_t)count;
+    ctx->stats.queries += n_queries;
+    done += count;
+  }
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_sync(sfm_hip_ctx* ctx) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  fold_qcounts(ctx);
+  return SFM_HIP_OK;
+}
+
+void* sfm_hip_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void sfm_hip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int sfm_hip_set_profiling(sfm_hip_ctx* ctx, int enabled) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  ctx->profiling = enabled != 0;
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_get_stats(sfm_hip_ctx* ctx, sfm_hip_stats* out) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (!out) return fail(ctx, SFM_HIP_ERR_INVALID, "out is null");
+  int rc = sfm_hip_sync(ctx);
+  if (rc) return rc;
+  if ((rc = fold_timed(ctx))) return rc;
+  *out = ctx->stats;
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_reset_stats(sfm_hip_ctx* ctx) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  int rc = sfm_hip_sync(ctx);
+  if (rc) return rc;
+  if ((rc = fold_timed(ctx))) return rc;
+  ctx->stats = sfm_hip_stats{};
+  return SFM_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def kat_cases():
+    with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+        return json.load(f)["cases"]
+
+
+def kat_descriptors(rows):
+    a = np.zeros((len(rows), 128), np.float32)
+    for i, r in enumerate(rows):
+        a[i, :3] = r
+    return a
+
+
+@pytest.fixture(scope="session")
+def matcher():
+    """One GPU context for the whole session (GPU tests only)."""
+    import sfm_amd
+    m = sfm_amd.Matcher(0)
+    yield m
+    m.close()
