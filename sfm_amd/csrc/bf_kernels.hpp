@@ -419,136 +419,242 @@ __device__ __forceinline__ double excluded_lower_bound(uint32_t boundkey, uint32
   return bv * (1.0 - 160.0 * u) - 450.0 * u * ((double)nq + (double)nomax);
 }
 
-struct QueueEntry { int32_t pair; int32_t dir_q; };  // dir_q = dir<<30 | query
-
-// DIR 0: queries are rows of X (lists from rowpart), candidates are rows of Y.
-// DIR 1: queries are rows of Y (lists from colpart), candidates are rows of X.
-// Four lanes per query, one candidate each.
-template <int DIR>
-__global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pairs, double ratio,
-                                                QueueEntry* __restrict__ queue, uint32_t* __restrict__ qcount) {
-  const PairDev& P = pairs[blockIdx.y];
-  const int nq = DIR == 0 ? P.na : P.nb;
-  const int no = DIR == 0 ? P.nb : P.na;
-  const int q = blockIdx.x * 64 + (threadIdx.x >> 2);
-  const int cl = threadIdx.x & 3;
-  if (q >= nq) return;   // whole groups of four leave together
-
-  uint32_t v0 = SENT, v1 = SENT, v2 = SENT, v3 = SENT, v4 = SENT;
-  uint32_t i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0;
-  uint32_t bound = SENT;
-  auto put = [&](uint32_t key, uint32_t idx) {
-    if (key < v4) {
-      v4 = key; i4 = idx;
-      if (v4 < v3) { uint32_t tv = v3; v3 = v4; v4 = tv; uint32_t ti = i3; i3 = i4; i4 = ti; }
-      if (v3 < v2) { uint32_t tv = v2; v2 = v3; v3 = tv; uint32_t ti = i2; i2 = i3; i3 = ti; }
-      if (v2 < v1) { uint32_t tv = v1; v1 = v2; v2 = tv; uint32_t ti = i1; i1 = i2; i2 = ti; }
-      if (v1 < v0) { uint32_t tv = v0; v0 = v1; v1 = tv; uint32_t ti = i0; i0 = i1; i1 = ti; }
-    }
-  };
-  if (DIR == 0) {
-    const size_t st = (size_t)P.na_pad;
-    for (int c = 0; c < P.nchunks; c++) {
-      const uint32_t* src = P.rowpart + (size_t)c * ROWPART_FIELDS * st + q;
-#pragma unroll
-      for (int e = 0; e < NCAND; e++) put(src[e * st], src[(NCAND + e) * st]);
-      const uint32_t b = src[2 * NCAND * st];
-      bound = bound < b ? bound : b;
-    }
-  } else {
-    const size_t st = (size_t)P.nb_pad;
-    const int nrb = P.na_pad / BM;
-    for (int rb = 0; rb < nrb; rb++) {
-      const uint32_t* src = P.colpart + (size_t)rb * 3 * st + q;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const uint32_t key = src[k * st];
-        const uint32_t lo = key & ~COL_MASK;
-        const uint32_t reg = lo & 15u, hh = (lo >> 4) & 1u, ww = lo >> 5;
-        const uint32_t row = (uint32_t)rb * BM + 32u * ww + (reg & 3u) + 8u * (reg >> 2) + 4u * hh;
-        put(key, row);
-        if (k == 2) bound = bound < key ? bound : key;
-      }
-    }
-  }
-  bound = bound < v4 ? bound : v4;
-
-  const uint32_t ck = cl == 0 ? v0 : cl == 1 ? v1 : cl == 2 ? v2 : v3;
-  const uint32_t ci = cl == 0 ? i0 : cl == 1 ? i1 : cl == 2 ? i2 : i3;
-  const float* qbase = DIR == 0 ? P.x : P.y;
-  const float* obase = DIR == 0 ? P.y : P.x;
-  Top2 t;
-  top2_init(t);
-  if (ck != SENT && (int)ci < no) {
-    float rsq = ref_sumsq(qbase + (size_t)q * DIM, obase + (size_t)ci * DIM);
-    top2_add(t, sqrtf(rsq), rsq, (int32_t)ci);
-  }
-#pragma unroll
-  for (int o = 1; o < 4; o <<= 1) {
-    Top2 u;
-    u.d1 = __shfl_xor(t.d1, o); u.i1 = __shfl_xor(t.i1, o); u.d2 = __shfl_xor(t.d2, o);
-    u.r1 = __shfl_xor(t.r1, o); u.r2 = __shfl_xor(t.r2, o);
-    top2_merge(t, u);
-  }
-  if (cl == 0) {
-    const float* qn = DIR == 0 ? P.xn : P.yn;
-    const float* on = DIR == 0 ? P.yn : P.xn;
-    const int opad = DIR == 0 ? P.nb_pad : P.na_pad;
-    bool safe = no <= NCAND || bound == SENT;
-    if (!safe) {
-      const uint32_t mask = DIR == 0 ? ROW_MASK : COL_MASK;
-      safe = (double)t.r2 <= excluded_lower_bound(bound, mask, qn[q], on[opad]);
-    }
-    const bool accept = (double)t.d1 < ratio * (double)t.d2;   // brute_force_matcher.cc:35
-    int32_t* best = DIR == 0 ? P.fwd_best : P.rev_best;
-    float* dist = DIR == 0 ? P.fwd_dist : P.rev_dist;
-    best[q] = accept ? t.i1 : -1;
-    dist[q] = t.d1;
-    if (!safe) {
-      uint32_t pos = atomicAdd(qcount, 1u);
-      queue[pos].pair = blockIdx.y;
-      queue[pos].dir_q = (DIR << 30) | q;
-    }
-  }
+// Running top-5 of (key, index) pairs, ascending by key; branch-free insertion.
+struct Top5 {
+  uint32_t v0, v1, v2, v3, v4;
+  uint32_t i0, i1, i2, i3, i4;
+};
+__device__ __forceinline__ void top5_init(Top5& t) {
+  t.v0 = t.v1 = t.v2 = t.v3 = t.v4 = SENT;
+  t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
+}
+__device__ __forceinline__ void cswap(uint32_t& va, uint32_t& ia, uint32_t& vb, uint32_t& ib) {
+  // afterwards va <= vb
+  const bool s = vb < va;
+  const uint32_t tv = s ? vb : va, ti = s ? ib : ia;
+  vb = s ? va : vb;
+  ib = s ? ia : ib;
+  va = tv;
+  ia = ti;
+}
+__device__ __forceinline__ void top5_put(Top5& t, uint32_t key, uint32_t idx) {
+  const bool s = key < t.v4;
+  t.v4 = s ? key : t.v4;
+  t.i4 = s ? idx : t.i4;
+  cswap(t.v3, t.i3, t.v4, t.i4);
+  cswap(t.v2, t.i2, t.v3, t.i3);
+  cswap(t.v1, t.i1, t.v2, t.i2);
+  cswap(t.v0, t.i0, t.v1, t.i1);
 }
 
-// Exact full scan for queued queries: one workgroup per query, threads take
-// columns j = tid, tid+256, ...; partial states merge order-independently.
-__global__ __launch_bounds__(256) void k_rescan(const PairDev* __restrict__ pairs, double ratio,
-                                                const QueueEntry* __restrict__ queue,
-                                                const uint32_t* __restrict__ qcount) {
-  __shared__ float qrow[DIM];
-  __shared__ Top2 part[256];
-  const uint32_t n = *qcount;
-  for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-    const QueueEntry qe = queue[e];
-    const PairDev& P = pairs[qe.pair];
-    const int dir = (qe.dir_q >> 30) & 1;
-    const int q = qe.dir_q & 0x3FFFFFFF;
-    const int no = dir == 0 ? P.nb : P.na;
-    const float* qbase = dir == 0 ? P.x : P.y;
-    const float* obase = dir == 0 ? P.y : P.x;
-    __syncthreads();
-    if (threadIdx.x < DIM) qrow[threadIdx.x] = qbase[(size_t)q * DIM + threadIdx.x];
-    __syncthreads();
-    Top2 t;
-    top2_init(t);
-    for (int j = threadIdx.x; j < no; j += 256) {
-      float rsq = ref_sumsq(qrow, obase + (size_t)j * DIM);
-      top2_add(t, sqrtf(rsq), rsq, j);
+constexpr int RR_QUERIES = 64;       // queries per workgroup of k_rerank
+constexpr int RR_SQ_STRIDE = 132;    // words per row of squares (128 + 4: conflict-free b128 reads)
+
+// k_rerank: grid (ceil(max queries / 64), pairs, directions), 256 threads.
+// Direction 0: queries are rows of X, lists come from rowpart, candidates are rows of Y.
+// Direction 1: queries are rows of Y, lists come from colpart, candidates are rows of X.
+//   A. four lanes per query merge the query's partial lists (a quarter each, then two
+//      shuffle rounds) into the best five keys and the bound key;
+//   B. the workgroup computes the 128 squared differences of every (query, candidate)
+//      with coalesced row loads, through LDS; one lane per (query, candidate) then adds
+//      them up in index order and takes the square root: src/metric.hpp:15-22;
+//   C. one lane per query applies brute_force_matcher.cc:26-38 to its four candidates
+//      and checks the completeness bound;
+//   D. queries that failed the check are re-answered by an exact scan of every
+//      candidate row, by the whole workgroup.
+__global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pairs, double ratio,
+                                                unsigned long long* __restrict__ rescanned) {
+  __shared__ __attribute__((aligned(16))) float sq[128 * RR_SQ_STRIDE];
+  __shared__ uint32_t cand[RR_QUERIES * NCAND];
+  __shared__ uint32_t bnd[RR_QUERIES];
+  __shared__ float res_r[RR_QUERIES * NCAND];
+  __shared__ int unsafe_q[RR_QUERIES];
+  __shared__ int n_unsafe;
+
+  const PairDev& P = pairs[blockIdx.y];
+  const int dir = blockIdx.z;
+  const int nq = dir == 0 ? P.na : P.nb;
+  const int no = dir == 0 ? P.nb : P.na;
+  const int q0 = blockIdx.x * RR_QUERIES;
+  if (q0 >= nq) return;
+  const float* qbase = dir == 0 ? P.x : P.y;
+  const float* obase = dir == 0 ? P.y : P.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) n_unsafe = 0;
+
+  // ---- A
+  {
+    const int ql = tid >> 2, sub = tid & 3;
+    const int q = q0 + ql;
+    Top5 t;
+    top5_init(t);
+    uint32_t bound = SENT;
+    if (q < nq) {
+      if (dir == 0) {
+        const size_t st = (size_t)P.na_pad;
+        for (int c = sub; c < P.nchunks; c += 4) {
+          const uint32_t* src = P.rowpart + (size_t)c * ROWPART_FIELDS * st + q;
+          uint32_t k[NCAND], ix[NCAND];
+#pragma unroll
+          for (int e = 0; e < NCAND; e++) {
+            k[e] = src[e * st];
+            ix[e] = src[(NCAND + e) * st];
+          }
+          const uint32_t b = src[2 * NCAND * st];
+#pragma unroll
+          for (int e = 0; e < NCAND; e++) top5_put(t, k[e], ix[e]);
+          bound = bound < b ? bound : b;
+        }
+      } else {
+        const size_t st = (size_t)P.nb_pad;
+        const int nrb = P.na_pad / BM;
+        for (int rb0 = sub; rb0 < nrb; rb0 += 16) {
+          uint32_t k[4][3];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int rb = rb0 + 4 * u;
+            const uint32_t* src = P.colpart + (size_t)rb * 3 * st + q;
+#pragma unroll
+            for (int e = 0; e < 3; e++) k[u][e] = rb < nrb ? src[e * st] : SENT;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int rb = rb0 + 4 * u;
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+              const uint32_t key = k[u][e];
+              const uint32_t lo = key & ~COL_MASK;
+              const uint32_t reg = lo & 15u, hh = (lo >> 4) & 1u, ww = lo >> 5;
+              top5_put(t, key, (uint32_t)rb * BM + 32u * ww + (reg & 3u) + 8u * (reg >> 2) + 4u * hh);
+            }
+            bound = bound < k[u][2] ? bound : k[u][2];   // a list's last key bounds what it left out
+          }
+        }
+      }
     }
-    part[threadIdx.x] = t;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) {
-        Top2 a = part[threadIdx.x];
-        top2_merge(a, part[threadIdx.x + s]);
-        part[threadIdx.x] = a;
+#pragma unroll
+    for (int o = 1; o < 4; o <<= 1) {
+      Top5 u;
+      u.v0 = __shfl_xor(t.v0, o); u.v1 = __shfl_xor(t.v1, o); u.v2 = __shfl_xor(t.v2, o);
+      u.v3 = __shfl_xor(t.v3, o); u.v4 = __shfl_xor(t.v4, o);
+      u.i0 = __shfl_xor(t.i0, o); u.i1 = __shfl_xor(t.i1, o); u.i2 = __shfl_xor(t.i2, o);
+      u.i3 = __shfl_xor(t.i3, o); u.i4 = __shfl_xor(t.i4, o);
+      const uint32_t ob = __shfl_xor(bound, o);
+      top5_put(t, u.v0, u.i0); top5_put(t, u.v1, u.i1); top5_put(t, u.v2, u.i2);
+      top5_put(t, u.v3, u.i3); top5_put(t, u.v4, u.i4);
+      bound = bound < ob ? bound : ob;
+    }
+    bound = bound < t.v4 ? bound : t.v4;
+    const uint32_t ck = sub == 0 ? t.v0 : sub == 1 ? t.v1 : sub == 2 ? t.v2 : t.v3;
+    const uint32_t ci = sub == 0 ? t.i0 : sub == 1 ? t.i1 : sub == 2 ? t.i2 : t.i3;
+    cand[tid] = (ck != SENT && (int)ci < no) ? ci : SENT;
+    if (sub == 0) bnd[ql] = bound;
+  }
+  __syncthreads();
+
+  // ---- B
+  {
+    const int w = tid >> 6, l = tid & 63, half = l >> 5, j = l & 31;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 4
+      for (int it = 0; it < 16; it++) {
+#pragma clang fp contract(off)
+        const int pl = w * 32 + it * 2 + half;      // (query, candidate) inside this pass
+        const int pi = pass * 128 + pl;
+        const uint32_t ci = cand[pi];
+        if (ci != SENT) {
+          const f32x4 u = reinterpret_cast<const f32x4*>(qbase + (size_t)(q0 + (pi >> 2)) * DIM)[j];
+          const f32x4 v = reinterpret_cast<const f32x4*>(obase + (size_t)ci * DIM)[j];
+          f32x4 d;
+          d.x = u.x - v.x; d.y = u.y - v.y; d.z = u.z - v.z; d.w = u.w - v.w;
+          d.x = d.x * d.x; d.y = d.y * d.y; d.z = d.z * d.z; d.w = d.w * d.w;
+          *reinterpret_cast<f32x4*>(sq + pl * RR_SQ_STRIDE + 4 * j) = d;
+        }
+      }
+      __syncthreads();
+      if (tid < 128) {
+#pragma clang fp contract(off)
+        const int pi = pass * 128 + tid;
+        float sum = __builtin_inff();
+        if (cand[pi] != SENT) {
+          const f32x4* s4 = reinterpret_cast<const f32x4*>(sq + tid * RR_SQ_STRIDE);
+          sum = 0.0f;
+#pragma unroll 8
+          for (int k = 0; k < DIM / 4; k++) {
+            const f32x4 v = s4[k];
+            sum = sum + v.x;
+            sum = sum + v.y;
+            sum = sum + v.z;
+            sum = sum + v.w;
+          }
+        }
+        res_r[pi] = sum;
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) {
-      Top2 r = part[0];
+  }
+
+  // ---- C
+  if (tid < RR_QUERIES && q0 + tid < nq) {
+    const int q = q0 + tid;
+    Top2 t;
+    top2_init(t);
+#pragma unroll
+    for (int c = 0; c < NCAND; c++) {
+      const uint32_t ci = cand[tid * NCAND + c];
+      if (ci != SENT) {
+        const float rsq = res_r[tid * NCAND + c];
+        top2_add(t, sqrtf(rsq), rsq, (int32_t)ci);
+      }
+    }
+    const float* qn = dir == 0 ? P.xn : P.yn;
+    const float* on = dir == 0 ? P.yn : P.xn;
+    const int opad = dir == 0 ? P.nb_pad : P.na_pad;
+    const uint32_t bound = bnd[tid];
+    bool safe = no <= NCAND || bound == SENT;
+    if (!safe) {
+      const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
+      safe = (double)t.r2 <= excluded_lower_bound(bound, mask, qn[q], on[opad]);
+    }
+    const bool accept = (double)t.d1 < ratio * (double)t.d2;   // brute_force_matcher.cc:35
+    int32_t* best = dir == 0 ? P.fwd_best : P.rev_best;
+    float* dist = dir == 0 ? P.fwd_dist : P.rev_dist;
+    best[q] = accept ? t.i1 : -1;
+    dist[q] = t.d1;
+    if (!safe) unsafe_q[atomicAdd(&n_unsafe, 1)] = q;
+  }
+  __syncthreads();
+
+  // ---- D
+  const int nu = n_unsafe;
+  if (nu == 0) return;
+  if (tid == 0) atomicAdd(rescanned, (unsigned long long)nu);
+  float* qrow = sq;                                        // 128 floats
+  Top2* part = reinterpret_cast<Top2*>(sq + 128);          // 256 partial states
+  for (int e = 0; e < nu; e++) {
+    const int q = unsafe_q[e];
+    __syncthreads();
+    if (tid < DIM) qrow[tid] = qbase[(size_t)q * DIM + tid];
+    __syncthreads();
+    Top2 t;
+    top2_init(t);
+    for (int jj = tid; jj < no; jj += 256) {
+      const float rsq = ref_sumsq(qrow, obase + (size_t)jj * DIM);
+      top2_add(t, sqrtf(rsq), rsq, jj);
+    }
+    part[tid] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        Top2 a = part[tid];
+        top2_merge(a, part[tid + s]);
+        part[tid] = a;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const Top2 r = part[0];
       const bool accept = (double)r.d1 < ratio * (double)r.d2;
       int32_t* best = dir == 0 ? P.fwd_best : P.rev_best;
       float* dist = dir == 0 ? P.fwd_dist : P.rev_dist;
@@ -561,7 +667,8 @@ __global__ __launch_bounds__(256) void k_rescan(const PairDev* __restrict__ pair
 // Cross-check (brute_force_matcher.cc:64-80) and ordered compaction.  A forward
 // match (i -> j) is kept when the reverse direction matched j back to i, or
 // when j has no surviving reverse match and i == 0 (the reference's map_[j]
-// default-inserts 0).  One workgroup of 1024 threads per pair.
+// default-inserts 0).  One workgroup of 1024 threads per pair; every thread owns
+// eight consecutive rows per sweep, so output order is ascending row order.
 __global__ __launch_bounds__(1024) void k_cross_compact(const PairDev* __restrict__ pairs, int cross_check,
                                                         int32_t* __restrict__ out_counts,
                                                         int32_t* __restrict__ out_lhs,
@@ -574,31 +681,53 @@ __global__ __launch_bounds__(1024) void k_cross_compact(const PairDev* __restric
   const size_t ob = (size_t)P.out_slot * (size_t)out_stride;
   if (tid == 0) base_s = 0;
   __syncthreads();
-  for (int i0 = 0; i0 < P.na; i0 += 1024) {
-    const int i = i0 + tid;
-    int j = -1;
-    float d = 0.f;
-    bool keep = false;
-    if (i < P.na) {
-      j = P.fwd_best[i];
-      d = P.fwd_dist[i];
-      keep = j >= 0;
-      if (keep && cross_check) {
-        const int rb = P.rev_best[j];
-        keep = rb == i || (rb < 0 && i == 0);
-      }
+  for (int i0 = 0; i0 < P.na; i0 += 8192) {
+    const int ib = i0 + tid * 8;     // fwd arrays are padded to a multiple of 128 rows: vector loads stay in bounds
+    int j[8];
+    float d[8];
+    bool keep[8];
+    if (ib < P.na) {
+      const int4 a = *reinterpret_cast<const int4*>(P.fwd_best + ib);
+      const int4 b = *reinterpret_cast<const int4*>(P.fwd_best + ib + 4);
+      const float4 da = *reinterpret_cast<const float4*>(P.fwd_dist + ib);
+      const float4 db = *reinterpret_cast<const float4*>(P.fwd_dist + ib + 4);
+      j[0] = a.x; j[1] = a.y; j[2] = a.z; j[3] = a.w; j[4] = b.x; j[5] = b.y; j[6] = b.z; j[7] = b.w;
+      d[0] = da.x; d[1] = da.y; d[2] = da.z; d[3] = da.w; d[4] = db.x; d[5] = db.y; d[6] = db.z; d[7] = db.w;
     }
-    const unsigned long long m = __ballot(keep);
-    const int within = __popcll(m & ((1ull << l) - 1ull));
-    if (l == 0) wsum[wv] = __popcll(m);
+    int rbv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = ib + k;
+      keep[k] = ib < P.na && i < P.na && j[k] >= 0;
+      rbv[k] = (keep[k] && cross_check) ? P.rev_best[j[k]] : 0;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = ib + k;
+      if (keep[k] && cross_check) keep[k] = rbv[k] == i || (rbv[k] < 0 && i == 0);
+      cnt += keep[k] ? 1 : 0;
+    }
+    // exclusive scan of cnt over the workgroup
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (l >= o) incl += v;
+    }
+    if (l == 63) wsum[wv] = incl;
     __syncthreads();
     int before = base_s;
     for (int k = 0; k < wv; k++) before += wsum[k];
-    if (keep) {
-      const size_t o = ob + (size_t)(before + within);
-      out_lhs[o] = i;
-      out_rhs[o] = j;
-      out_dist[o] = d;
+    int pos = before + incl - cnt;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (keep[k]) {
+        const size_t o = ob + (size_t)pos++;
+        out_lhs[o] = ib + k;
+        out_rhs[o] = j[k];
+        out_dist[o] = d[k];
+      }
     }
     __syncthreads();
     if (tid == 0) {

@@ -44,15 +44,14 @@ struct sfm_hip_ctx {
   std::string last_error;
 
   // grow-only device work space
-  DevBuf pairs_dev, blocks_dev, rowpart, colpart, best, queue, qcount, out_dev;
+  DevBuf tables_dev, rowpart, colpart, best, out_dev;
+  unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
+  std::vector<char> tables_shadow;               // what tables_dev currently holds
   // pinned staging for the per-batch tables, two slots
   void* stage_host[2] = {nullptr, nullptr};
   size_t stage_bytes[2] = {0, 0};
   hipEvent_t stage_free[2] = {nullptr, nullptr};
   int stage_slot = 0;
-  // pinned landing zone for per-batch rescan counts
-  uint32_t* qcount_host = nullptr;
-  size_t qcount_host_cap = 0, qcount_host_used = 0;
 
   bool profiling = false;
   std::vector<TimedLaunch> timed;
@@ -163,10 +162,22 @@ int fold_timed(sfm_hip_ctx* ctx) {
   return SFM_HIP_OK;
 }
 
-int fold_qcounts(sfm_hip_ctx* ctx) {
-  for (size_t i = 0; i < ctx->qcount_host_used; i++) ctx->stats.rescanned_queries += ctx->qcount_host[i];
-  ctx->qcount_host_used = 0;
-  return SFM_HIP_OK;
+// Device address through which a kernel can write a host output buffer
+// directly, or nullptr when the buffer is ordinary pageable memory.
+void* device_view_of_host(void* host) {
+  if (!host) return nullptr;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, host) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (a.type != hipMemoryTypeHost) return nullptr;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return d;
 }
 
 }  // namespace
@@ -203,6 +214,8 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&ctx->stage_free[s], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->rescanned_dev, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(ctx->rescanned_dev, 0, sizeof(unsigned long long));
   if (e != hipSuccess) {
     std::string msg = std::string("context set-up: ") + hipGetErrorString(e);
     delete ctx;
@@ -217,14 +230,13 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->images) free_image(kv.second);
-  for (DevBuf* b : {&ctx->pairs_dev, &ctx->blocks_dev, &ctx->rowpart, &ctx->colpart, &ctx->best, &ctx->queue,
-                    &ctx->qcount, &ctx->out_dev})
+  for (DevBuf* b : {&ctx->tables_dev, &ctx->rowpart, &ctx->colpart, &ctx->best, &ctx->out_dev})
     if (b->p) (void)hipFree(b->p);
+  if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
   for (int s = 0; s < 2; s++) {
     if (ctx->stage_host[s]) (void)hipHostFree(ctx->stage_host[s]);
     if (ctx->stage_free[s]) (void)hipEventDestroy(ctx->stage_free[s]);
   }
-  if (ctx->qcount_host) (void)hipHostFree(ctx->qcount_host);
   for (auto& t : ctx->timed) {
     (void)hipEventDestroy(t.start);
     (void)hipEventDestroy(t.stop);
@@ -362,25 +374,51 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       max_nb = std::max(max_nb, pl.Y->n);
     }
     int rc;
-    if ((rc = ensure(ctx, ctx->pairs_dev, sizeof(PairDev) * count))) return rc;
-    if ((rc = ensure(ctx, ctx->blocks_dev, sizeof(BlockDev) * std::max<size_t>(n_blocks, 1)))) return rc;
+    const size_t pairs_bytes = align_up(sizeof(PairDev) * count, 256);
+    const size_t table_bytes = pairs_bytes + sizeof(BlockDev) * n_blocks;
+    if ((rc = ensure(ctx, ctx->tables_dev, table_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->rowpart, rowpart_words * 4))) return rc;
     if ((rc = ensure(ctx, ctx->colpart, colpart_words * 4))) return rc;
     if ((rc = ensure(ctx, ctx->best, best_words * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->queue, sizeof(QueueEntry) * std::max<size_t>(n_queries, 1)))) return rc;
-    if ((rc = ensure(ctx, ctx->qcount, 256))) return rc;
-    const size_t out_words = (size_t)count * (size_t)out_stride;
-    // counts | lhs | rhs | dist
-    if ((rc = ensure(ctx, ctx->out_dev, align_up((size_t)count * 4, 256) + 3 * align_up(out_words * 4, 256) + 256)))
-      return rc;
 
-    const size_t table_bytes = align_up(sizeof(PairDev) * count, 256) + sizeof(BlockDev) * n_blocks;
+    // Outputs: kernels write straight into the caller's buffers when those are
+    // pinned host memory; otherwise into a device staging area that is copied back.
+    const size_t out_words = (size_t)count * (size_t)out_stride;
+    const size_t o = (size_t)done * (size_t)out_stride;
+    int32_t* k_counts = (int32_t*)device_view_of_host(out_counts + done);
+    int32_t* k_lhs = (int32_t*)device_view_of_host(out_lhs_idx + o);
+    int32_t* k_rhs = (int32_t*)device_view_of_host(out_rhs_idx + o);
+    float* k_dist = out_dist ? (float*)device_view_of_host(out_dist + o) : nullptr;
+    const bool direct = k_counts && k_lhs && k_rhs && (k_dist || !out_dist);
+    if (!direct || !out_dist) {
+      // counts | lhs | rhs | dist
+      if ((rc = ensure(ctx, ctx->out_dev, align_up((size_t)count * 4, 256) + 3 * align_up(out_words * 4, 256) + 256)))
+        return rc;
+      char* ob = (char*)ctx->out_dev.p;
+      int32_t* d_counts = (int32_t*)ob;
+      ob += align_up((size_t)count * 4, 256);
+      int32_t* d_lhs = (int32_t*)ob;
+      ob += align_up(out_words * 4, 256);
+      int32_t* d_rhs = (int32_t*)ob;
+      ob += align_up(out_words * 4, 256);
+      float* d_dist = (float*)ob;
+      if (!direct) {
+        k_counts = d_counts;
+        k_lhs = d_lhs;
+        k_rhs = d_rhs;
+        k_dist = d_dist;
+      } else {
+        k_dist = d_dist;  // caller does not want distances: let the kernel write them to scratch
+      }
+    }
+
     const int slot = ctx->stage_slot;
     ctx->stage_slot ^= 1;
     HIP_TRY(ctx, hipEventSynchronize(ctx->stage_free[slot]));
     if ((rc = ensure_stage(ctx, slot, table_bytes))) return rc;
+    std::memset(ctx->stage_host[slot], 0, table_bytes);
     PairDev* hp = reinterpret_cast<PairDev*>(ctx->stage_host[slot]);
-    BlockDev* hb = reinterpret_cast<BlockDev*>((char*)ctx->stage_host[slot] + align_up(sizeof(PairDev) * count, 256));
+    BlockDev* hb = reinterpret_cast<BlockDev*>((char*)ctx->stage_host[slot] + pairs_bytes);
 
     uint32_t* rp = (uint32_t*)ctx->rowpart.p;
     uint32_t* cp = (uint32_t*)ctx->colpart.p;
@@ -423,7 +461,6 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
             b.col0 = col0;
             b.ncols = ncols;
             b.chunk = c;
-            b.pad_[0] = b.pad_[1] = b.pad_[2] = 0;
           }
         }
         flop += 2.0 * pl.X->n * (double)pl.Y->n * DIM;
@@ -432,13 +469,18 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
 
     // ---- queue the batch
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pairs_dev.p, hp, sizeof(PairDev) * count, hipMemcpyHostToDevice, st));
-    if (n_blocks)
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->blocks_dev.p, hb, sizeof(BlockDev) * n_blocks, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipEventRecord(ctx->stage_free[slot], st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->qcount.p, 0, 256, st));
+    // The device keeps the previous batch's tables; identical tables (the same
+    // pairs matched again) need no new upload.
+    const bool same_tables = ctx->tables_shadow.size() == table_bytes &&
+                             std::memcmp(ctx->tables_shadow.data(), ctx->stage_host[slot], table_bytes) == 0;
+    if (!same_tables) {
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->tables_dev.p, ctx->stage_host[slot], table_bytes, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipEventRecord(ctx->stage_free[slot], st));
+      ctx->tables_shadow.assign((char*)ctx->stage_host[slot], (char*)ctx->stage_host[slot] + table_bytes);
+    }
 
-    const PairDev* dp = (const PairDev*)ctx->pairs_dev.p;
+    const PairDev* dp = (const PairDev*)ctx->tables_dev.p;
+    const BlockDev* db = (const BlockDev*)((const char*)ctx->tables_dev.p + pairs_bytes);
     if (n_blocks) {
       TimedLaunch tl{};
       if (ctx->profiling) {
@@ -447,16 +489,13 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
         tl.flop = flop;
         HIP_TRY(ctx, hipEventRecord(tl.start, st));
       }
-      hipLaunchKernelGGL(k_distance_topk, dim3((unsigned)n_blocks), dim3(256), 0, st, dp,
-                         (const BlockDev*)ctx->blocks_dev.p);
+      hipLaunchKernelGGL(k_distance_topk, dim3((unsigned)n_blocks), dim3(256), 0, st, dp, db);
       HIP_TRY(ctx, hipGetLastError());
       if (ctx->profiling) {
         HIP_TRY(ctx, hipEventRecord(tl.stop, st));
         ctx->timed.push_back(tl);
       }
     }
-    QueueEntry* qu = (QueueEntry*)ctx->queue.p;
-    uint32_t* qc = (uint32_t*)ctx->qcount.p;
     // Pairs with an empty image still go through the re-rank step: with no
     // candidates every query comes out unmatched, as in the reference.  Their
     // partial lists were never written, so give them empty ones.
@@ -466,46 +505,24 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       HIP_TRY(ctx, hipMemsetAsync(hp[k].rowpart, 0xFF, pl.rowpart_words * 4, st));
       HIP_TRY(ctx, hipMemsetAsync(hp[k].colpart, 0xFF, pl.colpart_words * 4, st));
     }
-    if (max_na > 0) {
-      hipLaunchKernelGGL(k_rerank<0>, dim3((max_na + 63) / 64, count), dim3(256), 0, st, dp, ratio, qu, qc);
+    const int max_q = cross_check ? std::max(max_na, max_nb) : max_na;
+    if (max_q > 0) {
+      hipLaunchKernelGGL(k_rerank, dim3((max_q + RR_QUERIES - 1) / RR_QUERIES, count, cross_check ? 2 : 1), dim3(256), 0,
+                         st, dp, ratio, ctx->rescanned_dev);
       HIP_TRY(ctx, hipGetLastError());
     }
-    if (cross_check && max_nb > 0) {
-      hipLaunchKernelGGL(k_rerank<1>, dim3((max_nb + 63) / 64, count), dim3(256), 0, st, dp, ratio, qu, qc);
-      HIP_TRY(ctx, hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_rescan, dim3(512), dim3(256), 0, st, dp, ratio, (const QueueEntry*)qu, (const uint32_t*)qc);
+    hipLaunchKernelGGL(k_cross_compact, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
+                       k_rhs, k_dist, out_stride);
     HIP_TRY(ctx, hipGetLastError());
 
-    char* ob = (char*)ctx->out_dev.p;
-    int32_t* d_counts = (int32_t*)ob;
-    ob += align_up((size_t)count * 4, 256);
-    int32_t* d_lhs = (int32_t*)ob;
-    ob += align_up(out_words * 4, 256);
-    int32_t* d_rhs = (int32_t*)ob;
-    ob += align_up(out_words * 4, 256);
-    float* d_dist = (float*)ob;
-    hipLaunchKernelGGL(k_cross_compact, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, d_counts, d_lhs,
-                       d_rhs, d_dist, out_stride);
-    HIP_TRY(ctx, hipGetLastError());
-
-    const size_t o = (size_t)done * (size_t)out_stride;
-    HIP_TRY(ctx, hipMemcpyAsync(out_counts + done, d_counts, (size_t)count * 4, hipMemcpyDeviceToHost, st));
-    if (out_words) {
-      HIP_TRY(ctx, hipMemcpyAsync(out_lhs_idx + o, d_lhs, out_words * 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipMemcpyAsync(out_rhs_idx + o, d_rhs, out_words * 4, hipMemcpyDeviceToHost, st));
-      if (out_dist) HIP_TRY(ctx, hipMemcpyAsync(out_dist + o, d_dist, out_words * 4, hipMemcpyDeviceToHost, st));
-    }
-    // rescan count of this batch, folded into the statistics at the next sync
-    if (ctx->qcount_host_used == ctx->qcount_host_cap) {
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-      fold_qcounts(ctx);
-      if (!ctx->qcount_host) {
-        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->qcount_host, 4096 * sizeof(uint32_t), hipHostMallocDefault));
-        ctx->qcount_host_cap = 4096;
+    if (!direct) {
+      HIP_TRY(ctx, hipMemcpyAsync(out_counts + done, k_counts, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+      if (out_words) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_lhs_idx + o, k_lhs, out_words * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(out_rhs_idx + o, k_rhs, out_words * 4, hipMemcpyDeviceToHost, st));
+        if (out_dist) HIP_TRY(ctx, hipMemcpyAsync(out_dist + o, k_dist, out_words * 4, hipMemcpyDeviceToHost, st));
       }
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->qcount_host + ctx->qcount_host_used++, qc, 4, hipMemcpyDeviceToHost, st));
 
     ctx->stats.pairs += (uint64_t)count;
     ctx->stats.queries += n_queries;
@@ -518,7 +535,6 @@ int sfm_hip_sync(sfm_hip_ctx* ctx) {
   if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  fold_qcounts(ctx);
   return SFM_HIP_OK;
 }
 
@@ -544,6 +560,9 @@ int sfm_hip_get_stats(sfm_hip_ctx* ctx, sfm_hip_stats* out) {
   int rc = sfm_hip_sync(ctx);
   if (rc) return rc;
   if ((rc = fold_timed(ctx))) return rc;
+  unsigned long long r = 0;
+  HIP_TRY(ctx, hipMemcpy(&r, ctx->rescanned_dev, sizeof(r), hipMemcpyDeviceToHost));
+  ctx->stats.rescanned_queries = r;
   *out = ctx->stats;
   return SFM_HIP_OK;
 }
@@ -553,6 +572,7 @@ int sfm_hip_reset_stats(sfm_hip_ctx* ctx) {
   int rc = sfm_hip_sync(ctx);
   if (rc) return rc;
   if ((rc = fold_timed(ctx))) return rc;
+  HIP_TRY(ctx, hipMemset(ctx->rescanned_dev, 0, sizeof(unsigned long long)));
   ctx->stats = sfm_hip_stats{};
   return SFM_HIP_OK;
 }
