@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pairs-per-step", type=int, default=1,
+                    help="pairs handed to one sfm_hip_match_pairs call (default 1: the headline configuration)")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not bracket the distance kernel with HIP events in the timed region")
     args = ap.parse_args()
@@ -81,7 +83,7 @@ def main():
     m.upload(0, A)
     m.upload(1, B)
     upload_s = time.perf_counter() - t0
-    pairs = np.array([[0, 1]], np.int64)
+    pairs = np.array([[0, 1]] * args.pairs_per_step, np.int64)
 
     def barrier():
         if dist_on:
@@ -113,7 +115,7 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        total_pairs = args.steps * world
+        total_pairs = args.steps * world * args.pairs_per_step
         value = total_pairs / elapsed
         flop_per_launch = 2.0 * N_FEATURES * N_FEATURES * 128
         roof = None
@@ -122,7 +124,7 @@ def main():
             achieved = st["distance_flop"] / st["distance_launches"] / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                    "kernel": "k_distance_topk", "avg_launch_ms": avg_ms, "flop_per_launch": flop_per_launch}
+                    "kernel": "k_distance_topk", "avg_launch_ms": avg_ms, "flop_per_launch": flop_per_launch * args.pairs_per_step}
         planted_found = len(set(zip(got[0].tolist(), got[1].tolist())) & set(map(tuple, truth.tolist())))
         line = {
             "metric": "image pairs/sec, 8k x 8k 128-d descriptors",
@@ -131,7 +133,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "single synthetic pair, 8192x8192 128-d float descriptors, "
                                    "ratio 0.8 + cross-check (BASELINE.json configs[1])",
-                       "pairs_per_step_per_gpu": 1, "planted_matches": PLANTED, "matches_found": cnt,
+                       "pairs_per_step_per_gpu": args.pairs_per_step, "planted_matches": PLANTED, "matches_found": cnt,
                        "planted_found": planted_found, "parallelism": "pairs sharded over ranks, no collective"},
             "frac_of_fp32_mfma_peak_end_to_end": value / world * flop_per_launch / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "rescanned_queries_per_pair": st["rescanned_queries"] / max(1, st["pairs"]),

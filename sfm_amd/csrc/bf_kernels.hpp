@@ -25,11 +25,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 namespace sfm {
 
 constexpr int DIM = 128;             // floats per descriptor
 constexpr int BM = 128;              // rows of S per workgroup (4 waves x 32 rows)
 constexpr int SN = 64;               // columns of S per LDS stage (2 tiles of 32)
+constexpr int CHUNK_ALIGN = 2 * SN;  // chunks hold an even number of stages
 constexpr int IMG_PAD = 128;         // images are padded to a multiple of this many rows
 constexpr uint32_t SENT = 0xFFFFFFFFu;   // "empty" key, larger than every real key
 constexpr int ROW_IDX_BITS = 9;      // row lists: low bits = 32-column tile number inside the chunk
@@ -44,8 +47,8 @@ constexpr int ROWPART_FIELDS = 2 * NCAND + 1;  // keys, column indices, bound ke
 constexpr int LDS_STAGE_BYTES = SN * DIM * 4;                 // 32 KiB
 constexpr int LDS_COLBUF_WORDS = 4 * 2 * 3 * 32;              // per parity: wave, tile, k, lane
 constexpr int LDS_OFF_COLBUF = 2 * LDS_STAGE_BYTES;
-constexpr int LDS_OFF_NAH = LDS_OFF_COLBUF + 2 * LDS_COLBUF_WORDS * 4;
-constexpr int LDS_TOTAL = LDS_OFF_NAH + BM * 4;
+constexpr int LDS_OFF_NAH = LDS_OFF_COLBUF + 3 * LDS_COLBUF_WORDS * 4;   // three stages of column lists in flight
+constexpr int LDS_TOTAL = LDS_OFF_NAH;
 constexpr int ROWBUF_STRIDE = 97;    // 96 keys per row + 1 word so that rows fall on different banks
 
 // One image pair as the kernels see it.
@@ -79,10 +82,11 @@ struct BlockDev {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// Median of three; the compiler selects v_med3_u32 for this shape.
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t r;
-  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
+  return umin32(umax32(a, b), umax32(umin32(a, b), c));
 }
 
 // Insert x into the ascending triple (a <= b <= c), dropping the largest of the four.
@@ -149,9 +153,207 @@ __device__ __forceinline__ void stage_load(const float* __restrict__ ysrc, char*
   }
 }
 
+// Running top-5 of (key, index) pairs, ascending by key; branch-free insertion.
+struct Top5 {
+  uint32_t v0, v1, v2, v3, v4;
+  uint32_t i0, i1, i2, i3, i4;
+};
+__device__ __forceinline__ void top5_init(Top5& t) {
+  t.v0 = t.v1 = t.v2 = t.v3 = t.v4 = SENT;
+  t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
+}
+__device__ __forceinline__ void cswap(uint32_t& va, uint32_t& ia, uint32_t& vb, uint32_t& ib) {
+  // afterwards va <= vb
+  const bool s = vb < va;
+  const uint32_t tv = s ? vb : va, ti = s ? ib : ia;
+  vb = s ? va : vb;
+  ib = s ? ia : ib;
+  va = tv;
+  ia = ti;
+}
+__device__ __forceinline__ void top5_put(Top5& t, uint32_t key, uint32_t idx) {
+  const bool s = key < t.v4;
+  t.v4 = s ? key : t.v4;
+  t.i4 = s ? idx : t.i4;
+  cswap(t.v3, t.i3, t.v4, t.i4);
+  cswap(t.v2, t.i2, t.v3, t.i3);
+  cswap(t.v1, t.i1, t.v2, t.i2);
+  cswap(t.v0, t.i0, t.v1, t.i1);
+}
+
+// Value of v held by lane l^32, valid in lanes 0..31 (lanes 32..63 get their own back).
+__device__ __forceinline__ uint32_t other_half(uint32_t v) {
+  // swap(vdst, src) exchanges the upper half of vdst with the lower half of src; with both
+  // operands equal to v the second result holds v's upper half in every lane below 32.
+  auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return r[1];
+}
+
+// Bits of max(x, 0) for a finite x: negative floats are negative as integers.
+__device__ __forceinline__ uint32_t clamp_bits(float x) {
+  const int32_t i = (int32_t)__float_as_uint(x);
+  return (uint32_t)(i > 0 ? i : 0);
+}
+
+// One 16-byte LDS read whose completion the compiler does not track: the caller
+// retires it with lds_wait<N>() before the first use.  OFF is an immediate byte offset.
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f32x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+// Wait until at most N of this wave's LDS operations are still outstanding, and keep the
+// compiler from moving anything across the wait (it cannot see what the wait is for).
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Private candidate lists of one lane.
+struct LaneLists {
+  uint32_t r0[16], r1[16], r2[16];   // per accumulator row: three smallest keys over the columns seen so far
+};
+
+// One "tile block": the 65 MFMAs that produce tile N (32 rows x 32 columns of
+// squared distances) interleaved, step by step, with the vector epilogue of the
+// previous tile P, so that the vector work runs in the shadow of the matrix work
+// of the same wave.
+//
+//   accN = [ |x|^2 , 1 ] . [ 1 , |y|^2 ]           (one MFMA, k = 128..129)
+//        + sum_k (-2 x_k) y_k                       (64 MFMAs)
+//        = |x|^2 + |y|^2 - 2 x.y
+//
+// Step s (16 steps of 4 MFMAs) reads B fragment s+2 from LDS, retires fragment s,
+// issues its 4 MFMAs and folds accumulator register s of tile P into the lists:
+// row key (distance bits | column-tile number) into the lane's list of that row,
+// column key (distance bits | register number) into the lane's list of its column.
+// LDSOFF = byte offset of tile N's 32 rows inside the LDS stage buffers.
+// ROT: B fragment s lives in b[(s + ROT) % 3].  NEXTOFF >= 0: the tile that follows sits
+// in the same LDS stage at that offset, and its first two fragments are fetched by the
+// last two steps of this tile (it then runs with FIRST = false and ROT + 1).
+template <int LDSOFF, int S, int ROT, int NEXTOFF>
+__device__ __forceinline__ void tile_step(f32x16& accN, const f32x16& accP, const float (&a)[64], f32x4 (&b)[3],
+                                          const uint32_t (&X)[8], uint32_t tP, LaneLists& L, uint32_t& cl0,
+                                          uint32_t& cl1, uint32_t& cl2) {
+  if constexpr (S + 2 < 16) {
+    lds_read16<LDSOFF + ((S + 2) >> 3) * 256>(b[(S + 2 + ROT) % 3], X[(S + 2) & 7]);
+    lds_wait<2>();
+  } else if constexpr (NEXTOFF >= 0) {
+    lds_read16<NEXTOFF>(b[(S + 2 + ROT) % 3], X[S + 2 - 16]);
+    lds_wait<2>();
+  } else {
+    lds_wait<15 - S>();
+  }
+  const f32x4 bs = b[(S + ROT) % 3];
+  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * S + 0], bs.x, accN, 0, 0, 0);
+  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * S + 1], bs.y, accN, 0, 0, 0);
+  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * S + 2], bs.z, accN, 0, 0, 0);
+  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * S + 3], bs.w, accN, 0, 0, 0);
+#if defined(SFM_ABLATE_EPILOGUE)
+  asm volatile("" ::"v"(accP[S]));   // diagnostic build: keep the accumulator live, skip the list updates
+#elif defined(SFM_ABLATE_ROWS)
+  { const uint32_t gb = clamp_bits(accP[S]); insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)S); }
+#elif defined(SFM_ABLATE_COLS)
+  { const uint32_t gb = clamp_bits(accP[S]); insert3(L.r0[S], L.r1[S], L.r2[S], (gb & ROW_MASK) | tP); }
+#else
+  const uint32_t gb = clamp_bits(accP[S]);
+  insert3(L.r0[S], L.r1[S], L.r2[S], (gb & ROW_MASK) | tP);
+  insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)S);
+#endif
+  // Anchor this step's list updates here: without a use at this point the optimizer sinks
+  // them out of the MFMA shadow to the end of the stage.
+  asm volatile("" : "+v"(L.r0[S]), "+v"(L.r1[S]), "+v"(L.r2[S]), "+v"(cl0), "+v"(cl1), "+v"(cl2));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int LDSOFF, int ROT, int NEXTOFF, int... S>
+__device__ __forceinline__ void tile_steps(std::integer_sequence<int, S...>, f32x16& accN, const f32x16& accP,
+                                           const float (&a)[64], f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tP,
+                                           LaneLists& L, uint32_t& cl0, uint32_t& cl1, uint32_t& cl2) {
+  (tile_step<LDSOFF, S, ROT, NEXTOFF>(accN, accP, a, b, X, tP, L, cl0, cl1, cl2), ...);
+}
+
+template <int LDSOFF, bool FIRST, int NEXTOFF>
+__device__ __forceinline__ void tile_block(f32x16& accN, const f32x16& accP, const float (&a)[64], float an, float bn,
+                                           f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tP, LaneLists& L,
+                                           uint32_t& cl0, uint32_t& cl1, uint32_t& cl2) {
+  if constexpr (FIRST) {
+    lds_read16<LDSOFF>(b[0], X[0]);
+    lds_read16<LDSOFF>(b[1], X[1]);
+  }
+  f32x16 zero;
+#pragma unroll
+  for (int i = 0; i < 16; i++) zero[i] = 0.0f;
+  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(an, bn, zero, 0, 0, 0);
+  cl0 = cl1 = cl2 = SENT;
+  tile_steps<LDSOFF, FIRST ? 0 : 1, NEXTOFF>(std::make_integer_sequence<int, 16>{}, accN, accP, a, b, X, tP, L, cl0,
+                                              cl1, cl2);
+}
+
+// Finish the column lists of a tile: add the wave/half bits, merge the two half-waves
+// (they hold the other 16 rows of the same columns) and park the result in LDS.
+__device__ __forceinline__ void tile_columns_park(uint32_t cl0, uint32_t cl1, uint32_t cl2, uint32_t lowc, int h,
+                                                  uint32_t* cb) {
+  cl0 |= lowc;
+  cl1 |= lowc;
+  cl2 |= lowc;
+  const uint32_t p0 = other_half(cl0), p1 = other_half(cl1), p2 = other_half(cl2);
+  insert3(cl0, cl1, cl2, p0);
+  insert3(cl0, cl1, cl2, p1);
+  insert3(cl0, cl1, cl2, p2);
+  if (h == 0) {
+    cb[0] = cl0;
+    cb[32] = cl1;
+    cb[64] = cl2;
+  }
+}
+
+// Merge the four waves' column lists of one finished stage (64 columns, one lane
+// each) and store them.
+__device__ __forceinline__ void stage_columns_out(const uint32_t* cb, int l, uint32_t* dst, size_t nb_pad) {
+  const int ct = l >> 5, c = l & 31;
+  uint32_t k0 = cb[((0 * 2 + ct) * 3 + 0) * 32 + c];
+  uint32_t k1 = cb[((0 * 2 + ct) * 3 + 1) * 32 + c];
+  uint32_t k2 = cb[((0 * 2 + ct) * 3 + 2) * 32 + c];
+#pragma unroll
+  for (int wv = 1; wv < 4; wv++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[((wv * 2 + ct) * 3 + k) * 32 + c]);
+  dst[0] = k0;
+  dst[nb_pad] = k1;
+  dst[2 * nb_pad] = k2;
+}
+
+// One LDS stage (64 columns = two tiles).  CUR = which of the two stage buffers.
+template <int CUR>
+__device__ __forceinline__ void stage_block(f32x16& accA, f32x16& accB, const float (&a)[64], float an, float bn0,
+                                            float bn1, const uint32_t (&X)[8], int g, uint32_t lowc, int h, int w,
+                                            int r, LaneLists& L, uint32_t* colbuf) {
+  uint32_t cl0, cl1, cl2;
+  f32x4 b[3];
+  constexpr int T0 = CUR * LDS_STAGE_BYTES, T1 = T0 + 32 * DIM * 4;
+  // tile (g, 0) into accA next to the epilogue of tile (g-1, 1) held in accB
+  tile_block<T0, true, T1>(accA, accB, a, an, bn0, b, X, (uint32_t)(2 * g - 1) & ~ROW_MASK, L, cl0, cl1, cl2);
+  tile_columns_park(cl0, cl1, cl2, lowc, h, colbuf + ((g + 2) % 3) * LDS_COLBUF_WORDS + ((w * 2 + 1) * 3) * 32 + r);
+  // tile (g, 1) into accB next to the epilogue of tile (g, 0)
+  tile_block<T1, false, -1>(accB, accA, a, an, bn1, b, X, (uint32_t)(2 * g), L, cl0, cl1, cl2);
+  tile_columns_park(cl0, cl1, cl2, lowc, h, colbuf + (g % 3) * LDS_COLBUF_WORDS + ((w * 2 + 0) * 3) * 32 + r);
+}
+
+#ifdef SFM_K1_STAMPS
+// Diagnostic build only (tools/k1_debug.hip): per workgroup start/end clocks.
+__device__ unsigned long long* g_stamps;
+#endif
+
 __global__ __launch_bounds__(256, 2) void k_distance_topk(const PairDev* __restrict__ pairs,
                                                           const BlockDev* __restrict__ blocks) {
   __shared__ __attribute__((aligned(1024))) char smem[LDS_TOTAL];
+#ifdef SFM_K1_STAMPS
+  if (threadIdx.x == 0) {
+    g_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    g_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 
   const BlockDev blk = blocks[blockIdx.x];
   const PairDev& P = pairs[blk.pair];
@@ -161,7 +363,6 @@ __global__ __launch_bounds__(256, 2) void k_distance_topk(const PairDev* __restr
   const int r = l & 31;
   const int h = l >> 5;
 
-  float* nah = reinterpret_cast<float*>(smem + LDS_OFF_NAH);
   uint32_t* colbuf = reinterpret_cast<uint32_t*>(smem + LDS_OFF_COLBUF);
 
   const float* ybase = P.y + (size_t)blk.col0 * DIM;
@@ -170,171 +371,157 @@ __global__ __launch_bounds__(256, 2) void k_distance_topk(const PairDev* __restr
   // first stage on its way before anything else
   stage_load(ybase, smem, w, l);
 
-  // A operands: 16 x 16 bytes per lane
+  // A operands, scaled by -2 (exact): 16 x 16 bytes per lane
   float a[64];
   {
     const f32x4* xrow = reinterpret_cast<const f32x4*>(P.x + (size_t)(blk.row0 + 32 * w + r) * DIM);
 #pragma unroll
     for (int s = 0; s < 16; s++) {
       f32x4 v = xrow[2 * s + h];
-      a[4 * s + 0] = v.x;
-      a[4 * s + 1] = v.y;
-      a[4 * s + 2] = v.z;
-      a[4 * s + 3] = v.w;
+      a[4 * s + 0] = -2.0f * v.x;
+      a[4 * s + 1] = -2.0f * v.y;
+      a[4 * s + 2] = -2.0f * v.z;
+      a[4 * s + 3] = -2.0f * v.w;
     }
   }
-  if (tid < BM) nah[tid] = -0.5f * P.xn[blk.row0 + tid];
+  // operands of the norm MFMA: A = [|x_r|^2, 1], B = [1, |y_c|^2] over k = (h = 0, h = 1)
+  const float an = h == 0 ? P.xn[blk.row0 + 32 * w + r] : 1.0f;
 
-  // private row lists: 16 rows x 3 keys
-  uint32_t rl0[16], rl1[16], rl2[16];
+  LaneLists L;
 #pragma unroll
-  for (int i = 0; i < 16; i++) rl0[i] = rl1[i] = rl2[i] = SENT;
+  for (int i = 0; i < 16; i++) L.r0[i] = L.r1[i] = L.r2[i] = SENT;
 
   const uint32_t lowc = (uint32_t)((w << 5) | (h << 4));
-  const int c0 = h ^ (r & 15);
+  // LDS byte address of this lane's row inside a tile, for each of the 8 chunk positions it reads
+  uint32_t X[8];
+  {
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int c0 = h ^ (r & 15);
+#pragma unroll
+    for (int k = 0; k < 8; k++) X[k] = base + (uint32_t)(r * (DIM * 4) + ((c0 ^ (2 * k)) << 4));
+  }
   const float* ynp = P.yn + blk.col0 + r;
   float nb_next0 = ynp[0], nb_next1 = ynp[32];
+  uint32_t* colpart_dst = P.colpart + (size_t)(blk.row0 / BM) * 3 * P.nb_pad + blk.col0 + l;
 
-  __syncthreads();  // stage 0 landed (the barrier's fence drains the LDS-DMA), nah visible
+  // The epilogue of a tile runs one tile late.  accB starts as a dummy tile whose keys
+  // are huge; it lands in a column-list slot that is never read and in row lists where it
+  // can only ever be displaced (and if it is not, it is just one more candidate to re-rank).
+  f32x16 accA, accB;
+#pragma unroll
+  for (int i = 0; i < 16; i++) accB[i] = 2e30f;
 
-  for (int g = 0; g < nstages; g++) {
-    const int cur = g & 1;
-    char* buf = smem + cur * LDS_STAGE_BYTES;
-    const float nb0 = nb_next0, nb1 = nb_next1;
-    if (g + 1 < nstages) {
-      stage_load(ybase + (size_t)(g + 1) * SN * DIM, smem + (cur ^ 1) * LDS_STAGE_BYTES, w, l);
-      nb_next0 = ynp[(g + 1) * SN];
-      nb_next1 = ynp[(g + 1) * SN + 32];
-    }
-    // column lists of the previous stage: merge the four waves' lists, one thread per column
-    if (g > 0 && w == 0) {
-      const uint32_t* cb = colbuf + (cur ^ 1) * LDS_COLBUF_WORDS;
-      const int ct = l >> 5, c = l & 31;
-      uint32_t k0 = cb[((0 * 2 + ct) * 3 + 0) * 32 + c];
-      uint32_t k1 = cb[((0 * 2 + ct) * 3 + 1) * 32 + c];
-      uint32_t k2 = cb[((0 * 2 + ct) * 3 + 2) * 32 + c];
-#pragma unroll
-      for (int wv = 1; wv < 4; wv++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[((wv * 2 + ct) * 3 + k) * 32 + c]);
-      uint32_t* dst = P.colpart + (size_t)(blk.row0 / BM) * 3 * P.nb_pad + blk.col0 + (g - 1) * SN + l;
-      dst[0] = k0;
-      dst[(size_t)P.nb_pad] = k1;
-      dst[2 * (size_t)P.nb_pad] = k2;
-    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // stage 0 landed
 
+  // Chunks hold a multiple of 128 columns, so stages come in pairs and each stage body is
+  // compiled for a fixed LDS buffer (all LDS offsets are immediates).
+  for (int g = 0; g < nstages; g += 2) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) {
-      const float nbj = ct == 0 ? nb0 : nb1;
-      const uint32_t t = (uint32_t)(g * 2 + ct);
-      f32x16 acc;
-      {
-        const f32x4* np = reinterpret_cast<const f32x4*>(nah + 32 * w + 4 * h);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          f32x4 v = np[2 * q];
-          acc[4 * q + 0] = v.x;
-          acc[4 * q + 1] = v.y;
-          acc[4 * q + 2] = v.z;
-          acc[4 * q + 3] = v.w;
-        }
+    for (int u = 0; u < 2; u++) {
+      const int gg = g + u;
+      const float bn0 = h == 0 ? 1.0f : nb_next0;
+      const float bn1 = h == 0 ? 1.0f : nb_next1;
+      if (gg + 1 < nstages) {
+        stage_load(ybase + (size_t)(gg + 1) * SN * DIM, smem + (u ^ 1) * LDS_STAGE_BYTES, w, l);
+        nb_next0 = ynp[(gg + 1) * SN];
+        nb_next1 = ynp[(gg + 1) * SN + 32];
       }
-      const char* rowp = buf + (32 * ct + r) * (DIM * 4);
-#pragma unroll
-      for (int s = 0; s < 16; s++) {
-        f32x4 b = *reinterpret_cast<const f32x4*>(rowp + ((c0 ^ (2 * s)) << 4));
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s + 0], b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s + 1], b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s + 2], b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s + 3], b.w, acc, 0, 0, 0);
-      }
-      uint32_t cl0 = SENT, cl1 = SENT, cl2 = SENT;
-#pragma unroll
-      for (int reg = 0; reg < 16; reg++) {
-        float gq = fmaxf(fmaf(acc[reg], -2.0f, nbj), 0.0f);
-        uint32_t gb = __float_as_uint(gq);
-        insert3(rl0[reg], rl1[reg], rl2[reg], (gb & ROW_MASK) | t);
-        insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)reg);
-      }
-      cl0 |= lowc;
-      cl1 |= lowc;
-      cl2 |= lowc;
-      uint32_t p0 = __shfl_xor(cl0, 32), p1 = __shfl_xor(cl1, 32), p2 = __shfl_xor(cl2, 32);
-      insert3(cl0, cl1, cl2, p0);
-      insert3(cl0, cl1, cl2, p1);
-      insert3(cl0, cl1, cl2, p2);
-      if (h == 0) {
-        uint32_t* cb = colbuf + cur * LDS_COLBUF_WORDS + ((w * 2 + ct) * 3) * 32 + r;
-        cb[0] = cl0;
-        cb[32] = cl1;
-        cb[64] = cl2;
-      }
+      // column lists of stage gg-2 are complete (their last tile's epilogue ran during stage gg-1)
+      if (gg >= 2 && w == 0)
+        stage_columns_out(colbuf + ((gg - 2) % 3) * LDS_COLBUF_WORDS, l, colpart_dst + (gg - 2) * SN,
+                          (size_t)P.nb_pad);
+      if (u == 0)
+        stage_block<0>(accA, accB, a, an, bn0, bn1, X, gg, lowc, h, w, r, L, colbuf);
+      else
+        stage_block<1>(accA, accB, a, an, bn0, bn1, X, gg, lowc, h, w, r, L, colbuf);
+      // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
+      // compiler does not always drain it for __syncthreads(), so wait explicitly.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // next stage landed; everyone done reading this one
     }
-    __syncthreads();  // next stage landed; everyone done with this one; colbuf[cur] complete
   }
-
-  // column lists of the last stage
+  // epilogue of the last tile
+  {
+    uint32_t cl0 = SENT, cl1 = SENT, cl2 = SENT;
+    const uint32_t tP = (uint32_t)(2 * nstages - 1);
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint32_t gb = clamp_bits(accB[s]);
+      insert3(L.r0[s], L.r1[s], L.r2[s], (gb & ROW_MASK) | tP);
+      insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)s);
+    }
+    tile_columns_park(cl0, cl1, cl2, lowc, h,
+                      colbuf + ((nstages - 1) % 3) * LDS_COLBUF_WORDS + ((w * 2 + 1) * 3) * 32 + r);
+  }
+  __syncthreads();
   if (w == 0) {
-    const int cur = (nstages - 1) & 1;
-    const uint32_t* cb = colbuf + cur * LDS_COLBUF_WORDS;
-    const int ct = l >> 5, c = l & 31;
-    uint32_t k0 = cb[((0 * 2 + ct) * 3 + 0) * 32 + c];
-    uint32_t k1 = cb[((0 * 2 + ct) * 3 + 1) * 32 + c];
-    uint32_t k2 = cb[((0 * 2 + ct) * 3 + 2) * 32 + c];
-#pragma unroll
-    for (int wv = 1; wv < 4; wv++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[((wv * 2 + ct) * 3 + k) * 32 + c]);
-    uint32_t* dst = P.colpart + (size_t)(blk.row0 / BM) * 3 * P.nb_pad + blk.col0 + (nstages - 1) * SN + l;
-    dst[0] = k0;
-    dst[(size_t)P.nb_pad] = k1;
-    dst[2 * (size_t)P.nb_pad] = k2;
+    if (nstages >= 2)
+      stage_columns_out(colbuf + ((nstages - 2) % 3) * LDS_COLBUF_WORDS, l, colpart_dst + (nstages - 2) * SN,
+                        (size_t)P.nb_pad);
+    stage_columns_out(colbuf + ((nstages - 1) % 3) * LDS_COLBUF_WORDS, l, colpart_dst + (nstages - 1) * SN,
+                      (size_t)P.nb_pad);
   }
 
-  // row lists: through LDS (the stage buffers are free now), one thread per row
+  // row lists: through LDS (the stage buffers are free now), two threads per row
   uint32_t* rowbuf = reinterpret_cast<uint32_t*>(smem);
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
     const int R = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
     uint32_t* d = rowbuf + R * ROWBUF_STRIDE + r * 3;
-    d[0] = rl0[reg];
-    d[1] = rl1[reg];
-    d[2] = rl2[reg];
+    d[0] = L.r0[reg];
+    d[1] = L.r1[reg];
+    d[2] = L.r2[reg];
   }
   __syncthreads();
-  if (tid < BM) {
-    const uint32_t* src = rowbuf + tid * ROWBUF_STRIDE;
-    uint32_t v0 = SENT, v1 = SENT, v2 = SENT, v3 = SENT, v4 = SENT;
-    uint32_t i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0;
+  {
+    const int R = tid >> 1, half = tid & 1;
+    const uint32_t* src = rowbuf + R * ROWBUF_STRIDE + half * 48;
+    Top5 t5;
+    top5_init(t5);
     uint32_t lanebound = SENT;
-    for (int p = 0; p < 32; p++) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const uint32_t key = src[p * 3 + k];
-        if (k == 2) lanebound = lanebound < key ? lanebound : key;
-        if (key < v4) {
-          v4 = key;
-          i4 = ((key & ~ROW_MASK) << 5) + (uint32_t)p;
-          if (v4 < v3) { uint32_t tv = v3; v3 = v4; v4 = tv; uint32_t ti = i3; i3 = i4; i4 = ti; }
-          if (v3 < v2) { uint32_t tv = v2; v2 = v3; v3 = tv; uint32_t ti = i2; i2 = i3; i3 = ti; }
-          if (v2 < v1) { uint32_t tv = v1; v1 = v2; v2 = tv; uint32_t ti = i1; i1 = i2; i2 = ti; }
-          if (v1 < v0) { uint32_t tv = v0; v0 = v1; v1 = tv; uint32_t ti = i0; i0 = i1; i1 = ti; }
-        }
-      }
+#pragma unroll 4
+    for (int pp = 0; pp < 16; pp++) {
+      const uint32_t k0 = src[pp * 3 + 0], k1 = src[pp * 3 + 1], k2 = src[pp * 3 + 2];
+      const uint32_t p = (uint32_t)(half * 16 + pp);
+      top5_put(t5, k0, ((k0 & ~ROW_MASK) << 5) + p);
+      top5_put(t5, k1, ((k1 & ~ROW_MASK) << 5) + p);
+      top5_put(t5, k2, ((k2 & ~ROW_MASK) << 5) + p);
+      lanebound = lanebound < k2 ? lanebound : k2;
     }
-    const uint32_t bound = lanebound < v4 ? lanebound : v4;
-    uint32_t* dst = P.rowpart + (size_t)blk.chunk * ROWPART_FIELDS * P.na_pad + blk.row0 + tid;
-    const size_t st = (size_t)P.na_pad;
-    dst[0 * st] = v0;
-    dst[1 * st] = v1;
-    dst[2 * st] = v2;
-    dst[3 * st] = v3;
-    dst[4 * st] = (uint32_t)blk.col0 + i0;
-    dst[5 * st] = (uint32_t)blk.col0 + i1;
-    dst[6 * st] = (uint32_t)blk.col0 + i2;
-    dst[7 * st] = (uint32_t)blk.col0 + i3;
-    dst[8 * st] = bound;
+    {
+      Top5 u;
+      u.v0 = __shfl_xor(t5.v0, 1); u.v1 = __shfl_xor(t5.v1, 1); u.v2 = __shfl_xor(t5.v2, 1);
+      u.v3 = __shfl_xor(t5.v3, 1); u.v4 = __shfl_xor(t5.v4, 1);
+      u.i0 = __shfl_xor(t5.i0, 1); u.i1 = __shfl_xor(t5.i1, 1); u.i2 = __shfl_xor(t5.i2, 1);
+      u.i3 = __shfl_xor(t5.i3, 1); u.i4 = __shfl_xor(t5.i4, 1);
+      const uint32_t ob = __shfl_xor(lanebound, 1);
+      top5_put(t5, u.v0, u.i0); top5_put(t5, u.v1, u.i1); top5_put(t5, u.v2, u.i2);
+      top5_put(t5, u.v3, u.i3); top5_put(t5, u.v4, u.i4);
+      lanebound = lanebound < ob ? lanebound : ob;
+    }
+    if (half == 0) {
+      const uint32_t bound = lanebound < t5.v4 ? lanebound : t5.v4;
+      uint32_t* dst = P.rowpart + (size_t)blk.chunk * ROWPART_FIELDS * P.na_pad + blk.row0 + R;
+      const size_t st = (size_t)P.na_pad;
+      dst[0 * st] = t5.v0;
+      dst[1 * st] = t5.v1;
+      dst[2 * st] = t5.v2;
+      dst[3 * st] = t5.v3;
+      dst[4 * st] = (uint32_t)blk.col0 + t5.i0;
+      dst[5 * st] = (uint32_t)blk.col0 + t5.i1;
+      dst[6 * st] = (uint32_t)blk.col0 + t5.i2;
+      dst[7 * st] = (uint32_t)blk.col0 + t5.i3;
+      dst[8 * st] = bound;
+    }
   }
+#ifdef SFM_K1_STAMPS
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    g_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -417,34 +604,6 @@ __device__ __forceinline__ double excluded_lower_bound(uint32_t boundkey, uint32
   const double u = 5.9604644775390625e-8;
   double bv = (double)__uint_as_float(boundkey & mask);
   return bv * (1.0 - 160.0 * u) - 450.0 * u * ((double)nq + (double)nomax);
-}
-
-// Running top-5 of (key, index) pairs, ascending by key; branch-free insertion.
-struct Top5 {
-  uint32_t v0, v1, v2, v3, v4;
-  uint32_t i0, i1, i2, i3, i4;
-};
-__device__ __forceinline__ void top5_init(Top5& t) {
-  t.v0 = t.v1 = t.v2 = t.v3 = t.v4 = SENT;
-  t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
-}
-__device__ __forceinline__ void cswap(uint32_t& va, uint32_t& ia, uint32_t& vb, uint32_t& ib) {
-  // afterwards va <= vb
-  const bool s = vb < va;
-  const uint32_t tv = s ? vb : va, ti = s ? ib : ia;
-  vb = s ? va : vb;
-  ib = s ? ia : ib;
-  va = tv;
-  ia = ti;
-}
-__device__ __forceinline__ void top5_put(Top5& t, uint32_t key, uint32_t idx) {
-  const bool s = key < t.v4;
-  t.v4 = s ? key : t.v4;
-  t.i4 = s ? idx : t.i4;
-  cswap(t.v3, t.i3, t.v4, t.i4);
-  cswap(t.v2, t.i2, t.v3, t.i3);
-  cswap(t.v1, t.i1, t.v2, t.i2);
-  cswap(t.v0, t.i0, t.v1, t.i1);
 }
 
 constexpr int RR_QUERIES = 64;       // queries per workgroup of k_rerank
@@ -545,10 +704,15 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
       bound = bound < ob ? bound : ob;
     }
     bound = bound < t.v4 ? bound : t.v4;
-    const uint32_t ck = sub == 0 ? t.v0 : sub == 1 ? t.v1 : sub == 2 ? t.v2 : t.v3;
-    const uint32_t ci = sub == 0 ? t.i0 : sub == 1 ? t.i1 : sub == 2 ? t.i2 : t.i3;
-    cand[tid] = (ck != SENT && (int)ci < no) ? ci : SENT;
-    if (sub == 0) bnd[ql] = bound;
+    // The four lanes now hold the same five entries, but equal keys may sit in a different
+    // order in each lane: one lane alone names the candidates.
+    if (sub == 0) {
+      cand[tid + 0] = (t.v0 != SENT && (int)t.i0 < no) ? t.i0 : SENT;
+      cand[tid + 1] = (t.v1 != SENT && (int)t.i1 < no) ? t.i1 : SENT;
+      cand[tid + 2] = (t.v2 != SENT && (int)t.i2 < no) ? t.i2 : SENT;
+      cand[tid + 3] = (t.v3 != SENT && (int)t.i3 < no) ? t.i3 : SENT;
+      bnd[ql] = bound;
+    }
   }
   __syncthreads();
 

@@ -127,8 +127,8 @@ void plan_chunks(PairPlan& pl, int row_blocks_in_batch_estimate) {
   const int nb_pad = pl.Y->n_pad;
   const int target_blocks = 512;
   int want = (target_blocks + row_blocks_in_batch_estimate - 1) / std::max(1, row_blocks_in_batch_estimate);
-  want = std::max(1, std::min(want, nb_pad / SN));
-  int cols = (int)align_up((size_t)(nb_pad + want - 1) / want, SN);
+  want = std::max(1, std::min(want, nb_pad / CHUNK_ALIGN));
+  int cols = (int)align_up((size_t)(nb_pad + want - 1) / want, CHUNK_ALIGN);
   cols = std::min(cols, MAX_CHUNK_COLS);
   pl.chunk_cols = cols;
   pl.nchunks = (nb_pad + cols - 1) / cols;

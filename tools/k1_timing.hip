@@ -1,0 +1,62 @@
+// Diagnostic: per-workgroup clocks of k_distance_topk on a synthetic 8192x8192 pair.
+#define SFM_K1_STAMPS 1
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "../sfm_amd/csrc/bf_kernels.hpp"
+using namespace sfm;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+int main(int argc, char** argv) {
+  int na = argc > 1 ? atoi(argv[1]) : 8192, nb = argc > 2 ? atoi(argv[2]) : 8192, chunk = argc > 3 ? atoi(argv[3]) : 1024;
+  int reps = argc > 4 ? atoi(argv[4]) : 5;
+  int na_pad = na, nb_pad = nb;
+  std::vector<float> A((size_t)na * 128), B((size_t)nb * 128);
+  unsigned s = 12345; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
+  for (auto& v : A) v = rnd() * 0.125f; for (auto& v : B) v = rnd() * 0.125f;
+  float *dx, *dy, *dxn, *dyn;
+  CK(hipMalloc(&dx, (size_t)na_pad * 512)); CK(hipMalloc(&dy, (size_t)nb_pad * 512));
+  CK(hipMalloc(&dxn, (na_pad + 1) * 4)); CK(hipMalloc(&dyn, (nb_pad + 1) * 4));
+  CK(hipMemset(dxn, 0, (na_pad + 1) * 4)); CK(hipMemset(dyn, 0, (nb_pad + 1) * 4));
+  CK(hipMemcpy(dx, A.data(), (size_t)na * 512, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dy, B.data(), (size_t)nb * 512, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_norms, dim3((na_pad + 3) / 4), dim3(256), 0, 0, dx, dxn, na, na_pad);
+  hipLaunchKernelGGL(k_norms, dim3((nb_pad + 3) / 4), dim3(256), 0, 0, dy, dyn, nb, nb_pad);
+  int nchunks = (nb_pad + chunk - 1) / chunk, nrb = na_pad / BM;
+  uint32_t *rowpart, *colpart;
+  size_t rw = (size_t)nchunks * ROWPART_FIELDS * na_pad, cw = (size_t)nrb * 3 * nb_pad;
+  CK(hipMalloc(&rowpart, rw * 4)); CK(hipMalloc(&colpart, cw * 4));
+  PairDev P{}; P.x = dx; P.xn = dxn; P.y = dy; P.yn = dyn; P.rowpart = rowpart; P.colpart = colpart;
+  P.na = na; P.nb = nb; P.na_pad = na_pad; P.nb_pad = nb_pad; P.nchunks = nchunks; P.chunk_cols = chunk;
+  std::vector<BlockDev> blocks;
+  for (int c = 0; c < nchunks; c++) for (int rb = 0; rb < nrb; rb++) {
+    BlockDev b{}; b.pair = 0; b.row0 = rb * BM; b.col0 = c * chunk; b.ncols = std::min(chunk, nb_pad - c * chunk); b.chunk = c; blocks.push_back(b);
+  }
+  PairDev* dP; BlockDev* dB; unsigned long long* dS;
+  size_t nblk = blocks.size();
+  CK(hipMalloc(&dP, sizeof(P))); CK(hipMalloc(&dB, sizeof(BlockDev) * nblk)); CK(hipMalloc(&dS, nblk * 32));
+  CK(hipMemcpy(dP, &P, sizeof(P), hipMemcpyHostToDevice)); CK(hipMemcpy(dB, blocks.data(), sizeof(BlockDev) * nblk, hipMemcpyHostToDevice));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dS, sizeof(dS)));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<unsigned long long> st(nblk * 4);
+  for (int rep = 0; rep < reps; rep++) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_distance_topk, dim3(nblk), dim3(256), 0, 0, dP, dB);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(st.data(), dS, nblk * 32, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0, r0 = ~0ull, r1 = 0;
+    std::vector<double> dur, start;
+    for (size_t b = 0; b < nblk; b++) { t0 = std::min(t0, st[4*b]); t1 = std::max(t1, st[4*b+2]); r0 = std::min(r0, st[4*b+1]); r1 = std::max(r1, st[4*b+3]); }
+    for (size_t b = 0; b < nblk; b++) { dur.push_back((double)(st[4*b+2] - st[4*b])); start.push_back((double)(st[4*b] - t0)); }
+    std::sort(dur.begin(), dur.end()); std::sort(start.begin(), start.end());
+    double real_us = (r1 - r0) / 100.0;   // 100 MHz
+    printf("rep %d: event %.1f us | stamps: span %llu cyc, real %.1f us -> clock %.3f GHz | WG dur min %.0f med %.0f p90 %.0f max %.0f | start med %.0f p90 %.0f max %.0f | blocks %zu\n",
+           rep, ms * 1e3, t1 - t0, real_us, (t1 - t0) / real_us / 1e3, dur.front(), dur[nblk/2], dur[nblk*9/10], dur.back(), start[nblk/2], start[nblk*9/10], start.back(), nblk);
+  }
+  double tiles = (double)(na / 32) * (nb / 32);
+  printf("MFMA cycles per SIMD if perfectly packed: %.0f\n", tiles * 65 * 64 / 1024);
+  return 0;
+}
