@@ -15,7 +15,10 @@ LIBDIR = os.path.join(ROOT, "sfm_amd", "lib")
 LIB = os.path.join(LIBDIR, "libsfm_hip.so")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# -amdgpu-mfma-vgpr-form: MFMA results land in the vector half of the register file, where the
+# epilogue's vector instructions read them without v_accvgpr_read copies.
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _newer(target, sources):

@@ -25,31 +25,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include <utility>
 
 namespace sfm {
 
 constexpr int DIM = 128;             // floats per descriptor
-constexpr int BM = 128;              // rows of S per workgroup (4 waves x 32 rows)
-constexpr int SN = 64;               // columns of S per LDS stage (2 tiles of 32)
+constexpr int BM = 256;              // rows of S per workgroup (4 waves x 64 rows)
+constexpr int SN = 128;              // columns of S per LDS stage (4 tiles of 32)
 constexpr int CHUNK_ALIGN = 2 * SN;  // chunks hold an even number of stages
-constexpr int IMG_PAD = 128;         // images are padded to a multiple of this many rows
+constexpr int IMG_PAD = 256;         // images are padded to a multiple of this many rows
 constexpr uint32_t SENT = 0xFFFFFFFFu;   // "empty" key, larger than every real key
 constexpr int ROW_IDX_BITS = 9;      // row lists: low bits = 32-column tile number inside the chunk
 constexpr uint32_t ROW_MASK = ~((1u << ROW_IDX_BITS) - 1u);
 constexpr int MAX_CHUNK_COLS = 32 << ROW_IDX_BITS;   // 16384
-constexpr int COL_IDX_BITS = 7;      // column lists: low bits = row inside the 128-row block (permuted)
+constexpr int COL_IDX_BITS = 8;      // column lists: low bits = row inside the 256-row block (permuted)
 constexpr uint32_t COL_MASK = ~((1u << COL_IDX_BITS) - 1u);
 constexpr float PAD_NORM = 1e30f;    // squared norm given to padding rows: never a near neighbour
 constexpr int NCAND = 4;             // candidates re-ranked exactly per query
 constexpr int ROWPART_FIELDS = 2 * NCAND + 1;  // keys, column indices, bound key
 
-constexpr int LDS_STAGE_BYTES = SN * DIM * 4;                 // 32 KiB
-constexpr int LDS_COLBUF_WORDS = 4 * 2 * 3 * 32;              // per parity: wave, tile, k, lane
+constexpr int LDS_STAGE_BYTES = SN * DIM * 4;                 // 64 KiB
+constexpr int LDS_COLBUF_WORDS = 4 * 4 * 3 * 32;              // per parity: wave, tile, k, lane
 constexpr int LDS_OFF_COLBUF = 2 * LDS_STAGE_BYTES;
-constexpr int LDS_OFF_NAH = LDS_OFF_COLBUF + 3 * LDS_COLBUF_WORDS * 4;   // three stages of column lists in flight
-constexpr int LDS_TOTAL = LDS_OFF_NAH;
+constexpr int LDS_TOTAL = LDS_OFF_COLBUF + 2 * LDS_COLBUF_WORDS * 4;
 constexpr int ROWBUF_STRIDE = 97;    // 96 keys per row + 1 word so that rows fall on different banks
+
+// Row of the 256-row block that a column-list key's low bits name.
+__host__ __device__ inline uint32_t col_key_row(uint32_t lo) {
+  const uint32_t reg = lo & 15u, h = (lo >> 4) & 1u, rt = (lo >> 5) & 1u, w = lo >> 6;
+  return 64u * w + 32u * rt + (reg & 3u) + 8u * (reg >> 2) + 4u * h;
+}
 
 // One image pair as the kernels see it.
 struct PairDev {
@@ -120,30 +126,39 @@ __global__ __launch_bounds__(256) void k_norms(const float* __restrict__ x, floa
 // ---------------------------------------------------------------------------
 // k_distance_topk
 //
-// Workgroup = 256 threads = 4 waves; wave w owns rows row0+32w .. +31 of the
-// block and keeps them as MFMA A-operands in 64 registers for the whole
-// kernel (lane (r, h) holds x[row r][4(2s+h)+e] for s<16, e<4; the k order
-// inside the contraction is permuted the same way for both operands).  The Y
-// columns of the chunk stream through LDS in stages of 64 rows x 512 B,
+// Measured on gfx950: vector instructions do not execute beside fp32 MFMAs, not
+// from the same wave and not from another wave of the SIMD (about 5 cycles of
+// matrix-pipe time per vector instruction, and ~10 more per switch between the
+// two kinds).  The kernel therefore spends as few vector instructions per tile as
+// it can, keeps them in one run per pair of tiles, and uses one wave per SIMD with
+// a large register budget instead of two waves that would only share the pipe.
+//
+// Workgroup = 256 threads = 4 waves; wave w owns rows row0+64w .. +63 (two row
+// tiles) and keeps them, scaled by -2, as MFMA A-operands in 128 registers for
+// the whole kernel (lane (r, h) holds x[row r][4(2s+h)+e] for s<16, e<4; the k
+// order inside the contraction is permuted the same way for both operands).
+// The Y columns of the chunk stream through LDS in stages of 128 rows x 512 B,
 // loaded by global_load_lds (no registers), double buffered, one barrier per
 // stage.  LDS rows are linear; 16-byte chunk c of row R is stored at chunk
-// position c ^ (R & 15) so that the ds_read_b128 of an operand fragment
-// (32 rows, same chunk) touches every bank group once.
+// position c ^ (R & 15) so that the ds_read_b128 of an operand fragment (32 rows,
+// same chunk) touches every bank group once.
 //
-// Accumulators start at -|x_i|^2/2, so after the K loop
-//     g = |y_j|^2 - 2*acc = |x_i|^2 + |y_j|^2 - 2 x_i.y_j .
+//   acc = [ |x|^2 , 1 ] . [ 1 , |y|^2 ]           (one MFMA, k = 128..129)
+//       + sum_k (-2 x_k) y_k                       (64 MFMAs)
+//       = |x|^2 + |y|^2 - 2 x.y
+//
 // In the 32x32 accumulator layout lane (c, h) holds column c and rows
-// (reg&3) + 8(reg>>2) + 4h.  Column minima are therefore lane-local; row
-// minima are spread over the 32 lanes of a half-wave, so every lane keeps a
-// private 3-entry list per row over the columns it sees (c, c+32, ...) and the
-// lists are merged once, at the end of the chunk.
+// (reg&3) + 8(reg>>2) + 4h.  Column minima are therefore lane-local; row minima
+// are spread over the 32 lanes of a half-wave, so every lane keeps a private
+// 3-entry list per row over the columns it sees (c, c+32, ...) and the lists are
+// merged once, at the end of the chunk.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void stage_load(const float* __restrict__ ysrc, char* ldsbuf, int w, int l) {
-  // Wave w fills rows 16w .. 16w+15 of the stage: 8 instructions of 1 KiB (2 rows) each.
+  // Wave w fills rows 32w .. 32w+31 of the stage: 16 instructions of 1 KiB (2 rows) each.
   const int pc = l & 31;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int q = w * 8 + i;
+  for (int i = 0; i < 16; i++) {
+    const int q = w * 16 + i;
     const int R = 2 * q + (l >> 5);
     const int lc = pc ^ (R & 15);
     const float* src = ysrc + (size_t)R * DIM + lc * 4;
@@ -209,94 +224,93 @@ __device__ __forceinline__ void lds_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// Private candidate lists of one lane.
+// Private row lists of one lane for one 32-row tile: per accumulator register (= row)
+// the three smallest keys over the columns this lane has seen.
 struct LaneLists {
-  uint32_t r0[16], r1[16], r2[16];   // per accumulator row: three smallest keys over the columns seen so far
+  uint32_t r0[16], r1[16], r2[16];
 };
 
-// One "tile block": the 65 MFMAs that produce tile N (32 rows x 32 columns of
-// squared distances) interleaved, step by step, with the vector epilogue of the
-// previous tile P, so that the vector work runs in the shadow of the matrix work
-// of the same wave.
-//
-//   accN = [ |x|^2 , 1 ] . [ 1 , |y|^2 ]           (one MFMA, k = 128..129)
-//        + sum_k (-2 x_k) y_k                       (64 MFMAs)
-//        = |x|^2 + |y|^2 - 2 x.y
-//
-// Step s (16 steps of 4 MFMAs) reads B fragment s+2 from LDS, retires fragment s,
-// issues its 4 MFMAs and folds accumulator register s of tile P into the lists:
-// row key (distance bits | column-tile number) into the lane's list of that row,
-// column key (distance bits | register number) into the lane's list of its column.
-// LDSOFF = byte offset of tile N's 32 rows inside the LDS stage buffers.
-// ROT: B fragment s lives in b[(s + ROT) % 3].  NEXTOFF >= 0: the tile that follows sits
-// in the same LDS stage at that offset, and its first two fragments are fetched by the
-// last two steps of this tile (it then runs with FIRST = false and ROT + 1).
-template <int LDSOFF, int S, int ROT, int NEXTOFF>
-__device__ __forceinline__ void tile_step(f32x16& accN, const f32x16& accP, const float (&a)[64], f32x4 (&b)[3],
-                                          const uint32_t (&X)[8], uint32_t tP, LaneLists& L, uint32_t& cl0,
-                                          uint32_t& cl1, uint32_t& cl2) {
+// Pin sixteen values to this program point (an empty asm that "modifies" them): the optimizer
+// otherwise moves pure arithmetic on them across the hand-placed waits and barriers.
+__device__ __forceinline__ void anchor16(uint32_t (&x)[16]) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+               "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+}
+
+// Step S of a tile pair: fetch B fragment S+2, retire fragment S, 4 MFMAs for each of the
+// wave's two row tiles.  TOFF = byte offset of the column tile inside its stage buffer;
+// ROT: fragment s lives in b[(s + ROT) % 3]; HAS_NEXT: the next column tile is in the same
+// stage (16 KiB further) and its first two fragments are fetched by the last two steps.
+template <int TOFF, int S, int ROT, bool HAS_NEXT>
+__device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const float (&a0)[64], const float (&a1)[64],
+                                          f32x4 (&b)[3], const uint32_t (&X)[8]) {
   if constexpr (S + 2 < 16) {
-    lds_read16<LDSOFF + ((S + 2) >> 3) * 256>(b[(S + 2 + ROT) % 3], X[(S + 2) & 7]);
+    lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(S + 2 + ROT) % 3], X[(S + 2) & 7]);
     lds_wait<2>();
-  } else if constexpr (NEXTOFF >= 0) {
-    lds_read16<NEXTOFF>(b[(S + 2 + ROT) % 3], X[S + 2 - 16]);
+  } else if constexpr (HAS_NEXT) {
+    lds_read16<TOFF + 32 * DIM * 4>(b[(S + 2 + ROT) % 3], X[S + 2 - 16]);
     lds_wait<2>();
   } else {
     lds_wait<15 - S>();
   }
   const f32x4 bs = b[(S + ROT) % 3];
-  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * S + 0], bs.x, accN, 0, 0, 0);
-  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * S + 1], bs.y, accN, 0, 0, 0);
-  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * S + 2], bs.z, accN, 0, 0, 0);
-  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * S + 3], bs.w, accN, 0, 0, 0);
-#if defined(SFM_ABLATE_EPILOGUE)
-  asm volatile("" ::"v"(accP[S]));   // diagnostic build: keep the accumulator live, skip the list updates
-#elif defined(SFM_ABLATE_ROWS)
-  { const uint32_t gb = clamp_bits(accP[S]); insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)S); }
-#elif defined(SFM_ABLATE_COLS)
-  { const uint32_t gb = clamp_bits(accP[S]); insert3(L.r0[S], L.r1[S], L.r2[S], (gb & ROW_MASK) | tP); }
-#else
-  const uint32_t gb = clamp_bits(accP[S]);
-  insert3(L.r0[S], L.r1[S], L.r2[S], (gb & ROW_MASK) | tP);
-  insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)S);
-#endif
-  // Anchor this step's list updates here: without a use at this point the optimizer sinks
-  // them out of the MFMA shadow to the end of the stage.
-  asm volatile("" : "+v"(L.r0[S]), "+v"(L.r1[S]), "+v"(L.r2[S]), "+v"(cl0), "+v"(cl1), "+v"(cl2));
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[4 * S + 0], bs.x, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * S + 0], bs.x, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[4 * S + 1], bs.y, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * S + 1], bs.y, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[4 * S + 2], bs.z, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * S + 2], bs.z, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[4 * S + 3], bs.w, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * S + 3], bs.w, acc1, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int LDSOFF, int ROT, int NEXTOFF, int... S>
-__device__ __forceinline__ void tile_steps(std::integer_sequence<int, S...>, f32x16& accN, const f32x16& accP,
-                                           const float (&a)[64], f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tP,
-                                           LaneLists& L, uint32_t& cl0, uint32_t& cl1, uint32_t& cl2) {
-  (tile_step<LDSOFF, S, ROT, NEXTOFF>(accN, accP, a, b, X, tP, L, cl0, cl1, cl2), ...);
+template <int TOFF, int ROT, bool HAS_NEXT, int... S>
+__device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32x16& acc0, f32x16& acc1,
+                                           const float (&a0)[64], const float (&a1)[64], f32x4 (&b)[3],
+                                           const uint32_t (&X)[8]) {
+  (pair_step<TOFF, S, ROT, HAS_NEXT>(acc0, acc1, a0, a1, b, X), ...);
 }
 
-template <int LDSOFF, bool FIRST, int NEXTOFF>
-__device__ __forceinline__ void tile_block(f32x16& accN, const f32x16& accP, const float (&a)[64], float an, float bn,
-                                           f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tP, LaneLists& L,
-                                           uint32_t& cl0, uint32_t& cl1, uint32_t& cl2) {
-  if constexpr (FIRST) {
-    lds_read16<LDSOFF>(b[0], X[0]);
-    lds_read16<LDSOFF>(b[1], X[1]);
+// Fold one finished accumulator tile into the lane's row lists and column list.
+// tv = column-tile number (row key low bits); RT = which of the wave's two row tiles.
+template <int RT>
+__device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLists& L, uint32_t& cl0, uint32_t& cl1,
+                                          uint32_t& cl2) {
+#pragma unroll
+  for (int reg = 0; reg < 16; reg++) {
+    const uint32_t gb = clamp_bits(acc[reg]);
+    insert3(L.r0[reg], L.r1[reg], L.r2[reg], (gb & ROW_MASK) | tv);
+    insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)(RT * 32 + reg));
+  }
+}
+
+// One column tile (32 columns) against the wave's 64 rows: 2 x 65 MFMAs, then the vector
+// epilogue for both accumulator tiles, then the column lists (over the wave's 64 rows) are
+// merged across the two half-waves and parked in LDS.
+template <int CT>
+__device__ __forceinline__ void tile_pair(const float (&a0)[64], const float (&a1)[64], float an0, float an1, float bn,
+                                          f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tv, LaneLists& L0,
+                                          LaneLists& L1, uint32_t lowc, int h, uint32_t* cb) {
+  constexpr int TOFF = CT * 32 * DIM * 4;
+  if constexpr (CT == 0) {
+    lds_read16<TOFF>(b[0], X[0]);
+    lds_read16<TOFF>(b[1], X[1]);
   }
   f32x16 zero;
 #pragma unroll
   for (int i = 0; i < 16; i++) zero[i] = 0.0f;
-  accN = __builtin_amdgcn_mfma_f32_32x32x2f32(an, bn, zero, 0, 0, 0);
-  cl0 = cl1 = cl2 = SENT;
-  tile_steps<LDSOFF, FIRST ? 0 : 1, NEXTOFF>(std::make_integer_sequence<int, 16>{}, accN, accP, a, b, X, tP, L, cl0,
-                                              cl1, cl2);
-}
+  f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
+  f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
+  pair_steps<TOFF, CT % 3, (CT < 3)>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X);
 
-// Finish the column lists of a tile: add the wave/half bits, merge the two half-waves
-// (they hold the other 16 rows of the same columns) and park the result in LDS.
-__device__ __forceinline__ void tile_columns_park(uint32_t cl0, uint32_t cl1, uint32_t cl2, uint32_t lowc, int h,
-                                                  uint32_t* cb) {
+  uint32_t cl0 = SENT, cl1 = SENT, cl2 = SENT;
+  tile_fold<0>(acc0, tv, L0, cl0, cl1, cl2);
+  tile_fold<1>(acc1, tv, L1, cl0, cl1, cl2);
   cl0 |= lowc;
   cl1 |= lowc;
   cl2 |= lowc;
+  // the other half-wave holds the other 32 rows of the same column: v_permlane32_swap, no LDS trip
   const uint32_t p0 = other_half(cl0), p1 = other_half(cl1), p2 = other_half(cl2);
   insert3(cl0, cl1, cl2, p0);
   insert3(cl0, cl1, cl2, p1);
@@ -306,46 +320,32 @@ __device__ __forceinline__ void tile_columns_park(uint32_t cl0, uint32_t cl1, ui
     cb[32] = cl1;
     cb[64] = cl2;
   }
+  // keep the epilogue where it is written: next to this tile pair, not sunk to the end of the stage
+  anchor16(L0.r0); anchor16(L0.r1); anchor16(L0.r2);
+  anchor16(L1.r0); anchor16(L1.r1); anchor16(L1.r2);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-// Merge the four waves' column lists of one finished stage (64 columns, one lane
-// each) and store them.
-__device__ __forceinline__ void stage_columns_out(const uint32_t* cb, int l, uint32_t* dst, size_t nb_pad) {
-  const int ct = l >> 5, c = l & 31;
-  uint32_t k0 = cb[((0 * 2 + ct) * 3 + 0) * 32 + c];
-  uint32_t k1 = cb[((0 * 2 + ct) * 3 + 1) * 32 + c];
-  uint32_t k2 = cb[((0 * 2 + ct) * 3 + 2) * 32 + c];
+// Merge the four waves' lists of 32 columns of a finished stage (one lane each) and store them.
+__device__ __forceinline__ void stage_columns_out(const uint32_t* cb, int ct, int c, uint32_t* dst, size_t nb_pad) {
+  uint32_t k0 = cb[((0 * 4 + ct) * 3 + 0) * 32 + c];
+  uint32_t k1 = cb[((0 * 4 + ct) * 3 + 1) * 32 + c];
+  uint32_t k2 = cb[((0 * 4 + ct) * 3 + 2) * 32 + c];
 #pragma unroll
   for (int wv = 1; wv < 4; wv++)
 #pragma unroll
-    for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[((wv * 2 + ct) * 3 + k) * 32 + c]);
+    for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[((wv * 4 + ct) * 3 + k) * 32 + c]);
   dst[0] = k0;
   dst[nb_pad] = k1;
   dst[2 * nb_pad] = k2;
 }
 
-// One LDS stage (64 columns = two tiles).  CUR = which of the two stage buffers.
-template <int CUR>
-__device__ __forceinline__ void stage_block(f32x16& accA, f32x16& accB, const float (&a)[64], float an, float bn0,
-                                            float bn1, const uint32_t (&X)[8], int g, uint32_t lowc, int h, int w,
-                                            int r, LaneLists& L, uint32_t* colbuf) {
-  uint32_t cl0, cl1, cl2;
-  f32x4 b[3];
-  constexpr int T0 = CUR * LDS_STAGE_BYTES, T1 = T0 + 32 * DIM * 4;
-  // tile (g, 0) into accA next to the epilogue of tile (g-1, 1) held in accB
-  tile_block<T0, true, T1>(accA, accB, a, an, bn0, b, X, (uint32_t)(2 * g - 1) & ~ROW_MASK, L, cl0, cl1, cl2);
-  tile_columns_park(cl0, cl1, cl2, lowc, h, colbuf + ((g + 2) % 3) * LDS_COLBUF_WORDS + ((w * 2 + 1) * 3) * 32 + r);
-  // tile (g, 1) into accB next to the epilogue of tile (g, 0)
-  tile_block<T1, false, -1>(accB, accA, a, an, bn1, b, X, (uint32_t)(2 * g), L, cl0, cl1, cl2);
-  tile_columns_park(cl0, cl1, cl2, lowc, h, colbuf + (g % 3) * LDS_COLBUF_WORDS + ((w * 2 + 0) * 3) * 32 + r);
-}
-
 #ifdef SFM_K1_STAMPS
-// Diagnostic build only (tools/k1_debug.hip): per workgroup start/end clocks.
+// Diagnostic build only (tools/k1_timing.hip): per workgroup start/end clocks.
 __device__ unsigned long long* g_stamps;
 #endif
 
-__global__ __launch_bounds__(256, 2) void k_distance_topk(const PairDev* __restrict__ pairs,
+__global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restrict__ pairs,
                                                           const BlockDev* __restrict__ blocks) {
   __shared__ __attribute__((aligned(1024))) char smem[LDS_TOTAL];
 #ifdef SFM_K1_STAMPS
@@ -371,149 +371,139 @@ __global__ __launch_bounds__(256, 2) void k_distance_topk(const PairDev* __restr
   // first stage on its way before anything else
   stage_load(ybase, smem, w, l);
 
-  // A operands, scaled by -2 (exact): 16 x 16 bytes per lane
-  float a[64];
+  // A operands of the wave's two row tiles, scaled by -2 (exact): 2 x 16 x 16 bytes per lane
+  float a0[64], a1[64];
   {
-    const f32x4* xrow = reinterpret_cast<const f32x4*>(P.x + (size_t)(blk.row0 + 32 * w + r) * DIM);
+    const f32x4* xr0 = reinterpret_cast<const f32x4*>(P.x + (size_t)(blk.row0 + 64 * w + r) * DIM);
+    const f32x4* xr1 = xr0 + 32 * (DIM / 4);
 #pragma unroll
     for (int s = 0; s < 16; s++) {
-      f32x4 v = xrow[2 * s + h];
-      a[4 * s + 0] = -2.0f * v.x;
-      a[4 * s + 1] = -2.0f * v.y;
-      a[4 * s + 2] = -2.0f * v.z;
-      a[4 * s + 3] = -2.0f * v.w;
+      const f32x4 u = xr0[2 * s + h], v = xr1[2 * s + h];
+      a0[4 * s + 0] = -2.0f * u.x; a0[4 * s + 1] = -2.0f * u.y; a0[4 * s + 2] = -2.0f * u.z; a0[4 * s + 3] = -2.0f * u.w;
+      a1[4 * s + 0] = -2.0f * v.x; a1[4 * s + 1] = -2.0f * v.y; a1[4 * s + 2] = -2.0f * v.z; a1[4 * s + 3] = -2.0f * v.w;
     }
   }
-  // operands of the norm MFMA: A = [|x_r|^2, 1], B = [1, |y_c|^2] over k = (h = 0, h = 1)
-  const float an = h == 0 ? P.xn[blk.row0 + 32 * w + r] : 1.0f;
-
-  LaneLists L;
+  // Park the A operands in the accumulator half of the register file: only MFMAs read them
+  // (an MFMA source may be an AGPR), which leaves the vector half to the lists and accumulators
+  // that the epilogue's vector instructions work on.
 #pragma unroll
-  for (int i = 0; i < 16; i++) L.r0[i] = L.r1[i] = L.r2[i] = SENT;
+  for (int i = 0; i < 64; i++) asm volatile("" : "+a"(a0[i]), "+a"(a1[i]));
+  // operands of the norm MFMA: A = [|x_r|^2, 1], B = [1, |y_c|^2] over k = (h = 0, h = 1)
+  const float an0 = h == 0 ? P.xn[blk.row0 + 64 * w + r] : 1.0f;
+  const float an1 = h == 0 ? P.xn[blk.row0 + 64 * w + 32 + r] : 1.0f;
 
-  const uint32_t lowc = (uint32_t)((w << 5) | (h << 4));
-  // LDS byte address of this lane's row inside a tile, for each of the 8 chunk positions it reads
-  uint32_t X[8];
+  LaneLists L0, L1;
+#pragma unroll
+  for (int i = 0; i < 16; i++) L0.r0[i] = L0.r1[i] = L0.r2[i] = L1.r0[i] = L1.r1[i] = L1.r2[i] = SENT;
+
+  const uint32_t lowc = (uint32_t)((w << 6) | (h << 4));
+  // LDS byte address of this lane's row inside a column tile, for each of the 8 chunk positions it
+  // reads, in stage buffer 0 (X0) and stage buffer 1 (X1)
+  uint32_t X0[8], X1[8];
   {
     const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int c0 = h ^ (r & 15);
 #pragma unroll
-    for (int k = 0; k < 8; k++) X[k] = base + (uint32_t)(r * (DIM * 4) + ((c0 ^ (2 * k)) << 4));
+    for (int k = 0; k < 8; k++) {
+      X0[k] = base + (uint32_t)(r * (DIM * 4) + ((c0 ^ (2 * k)) << 4));
+      X1[k] = X0[k] + LDS_STAGE_BYTES;
+    }
   }
   const float* ynp = P.yn + blk.col0 + r;
-  float nb_next0 = ynp[0], nb_next1 = ynp[32];
-  uint32_t* colpart_dst = P.colpart + (size_t)(blk.row0 / BM) * 3 * P.nb_pad + blk.col0 + l;
-
-  // The epilogue of a tile runs one tile late.  accB starts as a dummy tile whose keys
-  // are huge; it lands in a column-list slot that is never read and in row lists where it
-  // can only ever be displaced (and if it is not, it is just one more candidate to re-rank).
-  f32x16 accA, accB;
+  float nbn[4];
 #pragma unroll
-  for (int i = 0; i < 16; i++) accB[i] = 2e30f;
+  for (int ct = 0; ct < 4; ct++) nbn[ct] = ynp[32 * ct];
+  uint32_t* colpart_dst = P.colpart + (size_t)(blk.row0 / BM) * 3 * P.nb_pad + blk.col0 + 32 * w + r;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // stage 0 landed
 
-  // Chunks hold a multiple of 128 columns, so stages come in pairs and each stage body is
-  // compiled for a fixed LDS buffer (all LDS offsets are immediates).
+  // Chunks hold a multiple of 256 columns, so stages come in pairs and each stage body is
+  // compiled for a fixed LDS buffer.
+  auto stage_body = [&](auto UC, int gg) __attribute__((always_inline)) {
+    constexpr int u = decltype(UC)::value;
+    float bn[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) bn[ct] = h == 0 ? 1.0f : nbn[ct];
+    if (gg + 1 < nstages) {
+      stage_load(ybase + (size_t)(gg + 1) * SN * DIM, smem + (u ^ 1) * LDS_STAGE_BYTES, w, l);
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) nbn[ct] = ynp[(gg + 1) * SN + 32 * ct];
+    }
+    // column lists of the previous stage: each wave merges and stores 32 of its 128 columns
+    if (gg >= 1 && h == 0)
+      stage_columns_out(colbuf + (u ^ 1) * LDS_COLBUF_WORDS, w, r, colpart_dst + (gg - 1) * SN, (size_t)P.nb_pad);
+    uint32_t tv = (uint32_t)(4 * gg);
+    asm volatile("" : "+v"(tv));   // a VGPR, so that the row key is one v_and_or_b32
+    uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 3) * 32 + r;
+    f32x4 b[3];
+    const uint32_t (&X)[8] = u == 0 ? X0 : X1;
+    tile_pair<0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 96);
+    tile_pair<1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 96);
+    tile_pair<2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 96);
+    tile_pair<3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 96);
+    // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
+    // compiler does not always drain it for __syncthreads(), so wait explicitly.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // next stage landed; everyone done reading this one; column lists parked
+  };
+  // Chunks hold a multiple of 256 columns, so stages come in pairs and each stage body is
+  // compiled for a fixed LDS buffer.
   for (int g = 0; g < nstages; g += 2) {
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const int gg = g + u;
-      const float bn0 = h == 0 ? 1.0f : nb_next0;
-      const float bn1 = h == 0 ? 1.0f : nb_next1;
-      if (gg + 1 < nstages) {
-        stage_load(ybase + (size_t)(gg + 1) * SN * DIM, smem + (u ^ 1) * LDS_STAGE_BYTES, w, l);
-        nb_next0 = ynp[(gg + 1) * SN];
-        nb_next1 = ynp[(gg + 1) * SN + 32];
-      }
-      // column lists of stage gg-2 are complete (their last tile's epilogue ran during stage gg-1)
-      if (gg >= 2 && w == 0)
-        stage_columns_out(colbuf + ((gg - 2) % 3) * LDS_COLBUF_WORDS, l, colpart_dst + (gg - 2) * SN,
-                          (size_t)P.nb_pad);
-      if (u == 0)
-        stage_block<0>(accA, accB, a, an, bn0, bn1, X, gg, lowc, h, w, r, L, colbuf);
-      else
-        stage_block<1>(accA, accB, a, an, bn0, bn1, X, gg, lowc, h, w, r, L, colbuf);
-      // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
-      // compiler does not always drain it for __syncthreads(), so wait explicitly.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // next stage landed; everyone done reading this one
-    }
+    stage_body(std::integral_constant<int, 0>{}, g);
+    stage_body(std::integral_constant<int, 1>{}, g + 1);
   }
-  // epilogue of the last tile
-  {
-    uint32_t cl0 = SENT, cl1 = SENT, cl2 = SENT;
-    const uint32_t tP = (uint32_t)(2 * nstages - 1);
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const uint32_t gb = clamp_bits(accB[s]);
-      insert3(L.r0[s], L.r1[s], L.r2[s], (gb & ROW_MASK) | tP);
-      insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)s);
-    }
-    tile_columns_park(cl0, cl1, cl2, lowc, h,
-                      colbuf + ((nstages - 1) % 3) * LDS_COLBUF_WORDS + ((w * 2 + 1) * 3) * 32 + r);
-  }
-  __syncthreads();
-  if (w == 0) {
-    if (nstages >= 2)
-      stage_columns_out(colbuf + ((nstages - 2) % 3) * LDS_COLBUF_WORDS, l, colpart_dst + (nstages - 2) * SN,
-                        (size_t)P.nb_pad);
-    stage_columns_out(colbuf + ((nstages - 1) % 3) * LDS_COLBUF_WORDS, l, colpart_dst + (nstages - 1) * SN,
+  if (h == 0)
+    stage_columns_out(colbuf + ((nstages - 1) & 1) * LDS_COLBUF_WORDS, w, r, colpart_dst + (nstages - 1) * SN,
                       (size_t)P.nb_pad);
-  }
 
-  // row lists: through LDS (the stage buffers are free now), two threads per row
+  // row lists: through LDS (the stage buffers are free now), one thread per row
   uint32_t* rowbuf = reinterpret_cast<uint32_t*>(smem);
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
-    const int R = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    uint32_t* d = rowbuf + R * ROWBUF_STRIDE + r * 3;
-    d[0] = L.r0[reg];
-    d[1] = L.r1[reg];
-    d[2] = L.r2[reg];
+    const int R = 64 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    uint32_t* d0 = rowbuf + R * ROWBUF_STRIDE + r * 3;
+    uint32_t* d1 = d0 + 32 * ROWBUF_STRIDE;
+    d0[0] = L0.r0[reg]; d0[1] = L0.r1[reg]; d0[2] = L0.r2[reg];
+    d1[0] = L1.r0[reg]; d1[1] = L1.r1[reg]; d1[2] = L1.r2[reg];
   }
   __syncthreads();
   {
-    const int R = tid >> 1, half = tid & 1;
-    const uint32_t* src = rowbuf + R * ROWBUF_STRIDE + half * 48;
+    // Row tid: 32 sorted triples.  The five smallest keys of all 96 come from the lists whose
+    // head is among the five smallest heads, so rank the heads first and then add the tails of
+    // those five lists only.
+    const uint32_t* src = rowbuf + tid * ROWBUF_STRIDE;
     Top5 t5;
     top5_init(t5);
     uint32_t lanebound = SENT;
-#pragma unroll 4
-    for (int pp = 0; pp < 16; pp++) {
-      const uint32_t k0 = src[pp * 3 + 0], k1 = src[pp * 3 + 1], k2 = src[pp * 3 + 2];
-      const uint32_t p = (uint32_t)(half * 16 + pp);
-      top5_put(t5, k0, ((k0 & ~ROW_MASK) << 5) + p);
-      top5_put(t5, k1, ((k1 & ~ROW_MASK) << 5) + p);
-      top5_put(t5, k2, ((k2 & ~ROW_MASK) << 5) + p);
+#pragma unroll 8
+    for (int p = 0; p < 32; p++) {
+      top5_put(t5, src[p * 3], (uint32_t)p);
+      const uint32_t k2 = src[p * 3 + 2];
       lanebound = lanebound < k2 ? lanebound : k2;
     }
-    {
-      Top5 u;
-      u.v0 = __shfl_xor(t5.v0, 1); u.v1 = __shfl_xor(t5.v1, 1); u.v2 = __shfl_xor(t5.v2, 1);
-      u.v3 = __shfl_xor(t5.v3, 1); u.v4 = __shfl_xor(t5.v4, 1);
-      u.i0 = __shfl_xor(t5.i0, 1); u.i1 = __shfl_xor(t5.i1, 1); u.i2 = __shfl_xor(t5.i2, 1);
-      u.i3 = __shfl_xor(t5.i3, 1); u.i4 = __shfl_xor(t5.i4, 1);
-      const uint32_t ob = __shfl_xor(lanebound, 1);
-      top5_put(t5, u.v0, u.i0); top5_put(t5, u.v1, u.i1); top5_put(t5, u.v2, u.i2);
-      top5_put(t5, u.v3, u.i3); top5_put(t5, u.v4, u.i4);
-      lanebound = lanebound < ob ? lanebound : ob;
+    const uint32_t hp[5] = {t5.i0, t5.i1, t5.i2, t5.i3, t5.i4};
+    const uint32_t hv[5] = {t5.v0, t5.v1, t5.v2, t5.v3, t5.v4};
+#pragma unroll
+    for (int e = 0; e < 5; e++) {
+      const uint32_t k1 = hv[e] == SENT ? SENT : src[hp[e] * 3 + 1];
+      const uint32_t k2 = hv[e] == SENT ? SENT : src[hp[e] * 3 + 2];
+      top5_put(t5, k1, hp[e]);
+      top5_put(t5, k2, hp[e]);
     }
-    if (half == 0) {
-      const uint32_t bound = lanebound < t5.v4 ? lanebound : t5.v4;
-      uint32_t* dst = P.rowpart + (size_t)blk.chunk * ROWPART_FIELDS * P.na_pad + blk.row0 + R;
-      const size_t st = (size_t)P.na_pad;
-      dst[0 * st] = t5.v0;
-      dst[1 * st] = t5.v1;
-      dst[2 * st] = t5.v2;
-      dst[3 * st] = t5.v3;
-      dst[4 * st] = (uint32_t)blk.col0 + t5.i0;
-      dst[5 * st] = (uint32_t)blk.col0 + t5.i1;
-      dst[6 * st] = (uint32_t)blk.col0 + t5.i2;
-      dst[7 * st] = (uint32_t)blk.col0 + t5.i3;
-      dst[8 * st] = bound;
-    }
+    const uint32_t bound = lanebound < t5.v4 ? lanebound : t5.v4;
+    uint32_t* dst = P.rowpart + (size_t)blk.chunk * ROWPART_FIELDS * P.na_pad + blk.row0 + tid;
+    const size_t st = (size_t)P.na_pad;
+    const uint32_t c0 = (uint32_t)blk.col0;
+    dst[0 * st] = t5.v0;
+    dst[1 * st] = t5.v1;
+    dst[2 * st] = t5.v2;
+    dst[3 * st] = t5.v3;
+    dst[4 * st] = c0 + ((t5.v0 & ~ROW_MASK) << 5) + t5.i0;
+    dst[5 * st] = c0 + ((t5.v1 & ~ROW_MASK) << 5) + t5.i1;
+    dst[6 * st] = c0 + ((t5.v2 & ~ROW_MASK) << 5) + t5.i2;
+    dst[7 * st] = c0 + ((t5.v3 & ~ROW_MASK) << 5) + t5.i3;
+    dst[8 * st] = bound;
   }
 #ifdef SFM_K1_STAMPS
   __syncthreads();
@@ -682,9 +672,7 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
 #pragma unroll
             for (int e = 0; e < 3; e++) {
               const uint32_t key = k[u][e];
-              const uint32_t lo = key & ~COL_MASK;
-              const uint32_t reg = lo & 15u, hh = (lo >> 4) & 1u, ww = lo >> 5;
-              top5_put(t, key, (uint32_t)rb * BM + 32u * ww + (reg & 3u) + 8u * (reg >> 2) + 4u * hh);
+              top5_put(t, key, (uint32_t)rb * BM + col_key_row(key & ~COL_MASK));
             }
             bound = bound < k[u][2] ? bound : k[u][2];   // a list's last key bounds what it left out
           }

@@ -6,7 +6,7 @@ A, B, _ = synth.make_pair(300, 300, 150, seed=77)
 B[10] = B[20]; B[200:210] = A[5]; A[100] = A[101]
 A.tofile("/tmp/A.bin"); B.tofile("/tmp/B.bin")
 exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "k1_debug")
-for chunk in (128, 384):
+for chunk in (256, 512):
     print("chunk", chunk, flush=True)
     subprocess.run([exe, "/tmp/A.bin", "300", "/tmp/B.bin", "300", str(chunk)], check=False)
 A, B, _ = synth.make_pair(2048, 2048, 700, seed=3)

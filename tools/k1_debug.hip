@@ -14,7 +14,7 @@ static std::vector<float> readf(const char* p, size_t n) { std::vector<float> v(
 int main(int argc, char** argv) {
   int na = atoi(argv[2]), nb = atoi(argv[4]), chunk = atoi(argv[5]);
   auto A = readf(argv[1], (size_t)na * 128), B = readf(argv[3], (size_t)nb * 128);
-  int na_pad = (na + 127) / 128 * 128, nb_pad = (nb + 127) / 128 * 128;
+  int na_pad = (na + IMG_PAD - 1) / IMG_PAD * IMG_PAD, nb_pad = (nb + IMG_PAD - 1) / IMG_PAD * IMG_PAD;
   float *dx, *dy, *dxn, *dyn;
   CK(hipMalloc(&dx, (size_t)na_pad * 512)); CK(hipMalloc(&dy, (size_t)nb_pad * 512));
   CK(hipMalloc(&dxn, (na_pad + 1) * 4)); CK(hipMalloc(&dyn, (nb_pad + 1) * 4));
@@ -69,8 +69,7 @@ int main(int argc, char** argv) {
       bool found = false;
       for (int rb = 0; rb < nrb && !found; rb++) for (int k = 0; k < 3; k++) {
         uint32_t key = cp[((size_t)rb * 3 + k) * nb_pad + j]; if (key == SENT) continue;
-        uint32_t lo = key & ~COL_MASK, reg = lo & 15, hh = (lo >> 4) & 1, ww = lo >> 5;
-        int row = rb * BM + 32 * ww + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        int row = rb * BM + (int)col_key_row(key & ~COL_MASK);
         if (row == v[t].second) found = true;
       }
       if (!found && bad_cols++ < 10) printf("COL %d: rank-%d row %d (d2 %.8f) missing\n", j, t, v[t].second, v[t].first);

@@ -11,7 +11,7 @@ using namespace sfm;
 int main(int argc, char** argv) {
   int na = argc > 1 ? atoi(argv[1]) : 8192, nb = argc > 2 ? atoi(argv[2]) : 8192, chunk = argc > 3 ? atoi(argv[3]) : 1024;
   int reps = argc > 4 ? atoi(argv[4]) : 5;
-  int na_pad = na, nb_pad = nb;
+  int na_pad = (na + IMG_PAD - 1) / IMG_PAD * IMG_PAD, nb_pad = (nb + IMG_PAD - 1) / IMG_PAD * IMG_PAD;
   std::vector<float> A((size_t)na * 128), B((size_t)nb * 128);
   unsigned s = 12345; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
   for (auto& v : A) v = rnd() * 0.125f; for (auto& v : B) v = rnd() * 0.125f;
