@@ -641,33 +641,42 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
     if (q < nq) {
       if (dir == 0) {
         const size_t st = (size_t)P.na_pad;
-        for (int c = sub; c < P.nchunks; c += 4) {
-          const uint32_t* src = P.rowpart + (size_t)c * ROWPART_FIELDS * st + q;
-          uint32_t k[NCAND], ix[NCAND];
+        // two lists per trip to memory (loads first, then the inserts)
+        for (int c0 = sub; c0 < P.nchunks; c0 += 8) {
+          uint32_t k[2][NCAND], ix[2][NCAND], b[2];
 #pragma unroll
-          for (int e = 0; e < NCAND; e++) {
-            k[e] = src[e * st];
-            ix[e] = src[(NCAND + e) * st];
+          for (int u = 0; u < 2; u++) {
+            const int c = c0 + 4 * u;
+            const uint32_t* src = P.rowpart + (size_t)c * ROWPART_FIELDS * st + q;
+#pragma unroll
+            for (int e = 0; e < NCAND; e++) {
+              k[u][e] = c < P.nchunks ? src[e * st] : SENT;
+              ix[u][e] = c < P.nchunks ? src[(NCAND + e) * st] : 0u;
+            }
+            b[u] = c < P.nchunks ? src[2 * NCAND * st] : SENT;
           }
-          const uint32_t b = src[2 * NCAND * st];
 #pragma unroll
-          for (int e = 0; e < NCAND; e++) top5_put(t, k[e], ix[e]);
-          bound = bound < b ? bound : b;
+          for (int u = 0; u < 2; u++) {
+#pragma unroll
+            for (int e = 0; e < NCAND; e++) top5_put(t, k[u][e], ix[u][e]);
+            bound = bound < b[u] ? bound : b[u];
+          }
         }
       } else {
         const size_t st = (size_t)P.nb_pad;
         const int nrb = P.na_pad / BM;
-        for (int rb0 = sub; rb0 < nrb; rb0 += 16) {
-          uint32_t k[4][3];
+        // eight lists per trip to memory (loads first, then the inserts)
+        for (int rb0 = sub; rb0 < nrb; rb0 += 32) {
+          uint32_t k[8][3];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < 8; u++) {
             const int rb = rb0 + 4 * u;
             const uint32_t* src = P.colpart + (size_t)rb * 3 * st + q;
 #pragma unroll
             for (int e = 0; e < 3; e++) k[u][e] = rb < nrb ? src[e * st] : SENT;
           }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < 8; u++) {
             const int rb = rb0 + 4 * u;
 #pragma unroll
             for (int e = 0; e < 3; e++) {
@@ -709,20 +718,26 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
     const int w = tid >> 6, l = tid & 63, half = l >> 5, j = l & 31;
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
-#pragma unroll 4
+      // all of the pass's row loads first (one trip to memory), then the arithmetic
+      f32x4 uq[16], vc[16];
+      uint32_t cis[16];
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int pi = pass * 128 + w * 32 + it * 2 + half;
+        cis[it] = cand[pi];
+        const uint32_t cr = cis[it] != SENT ? cis[it] : 0u;   // any valid row; the result is not used
+        uq[it] = reinterpret_cast<const f32x4*>(qbase + (size_t)(q0 + (pi >> 2) < nq ? q0 + (pi >> 2) : q0) * DIM)[j];
+        vc[it] = reinterpret_cast<const f32x4*>(obase + (size_t)cr * DIM)[j];
+      }
+#pragma unroll
       for (int it = 0; it < 16; it++) {
 #pragma clang fp contract(off)
         const int pl = w * 32 + it * 2 + half;      // (query, candidate) inside this pass
-        const int pi = pass * 128 + pl;
-        const uint32_t ci = cand[pi];
-        if (ci != SENT) {
-          const f32x4 u = reinterpret_cast<const f32x4*>(qbase + (size_t)(q0 + (pi >> 2)) * DIM)[j];
-          const f32x4 v = reinterpret_cast<const f32x4*>(obase + (size_t)ci * DIM)[j];
-          f32x4 d;
-          d.x = u.x - v.x; d.y = u.y - v.y; d.z = u.z - v.z; d.w = u.w - v.w;
-          d.x = d.x * d.x; d.y = d.y * d.y; d.z = d.z * d.z; d.w = d.w * d.w;
-          *reinterpret_cast<f32x4*>(sq + pl * RR_SQ_STRIDE + 4 * j) = d;
-        }
+        const f32x4 u = uq[it], v = vc[it];
+        f32x4 d;
+        d.x = u.x - v.x; d.y = u.y - v.y; d.z = u.z - v.z; d.w = u.w - v.w;
+        d.x = d.x * d.x; d.y = d.y * d.y; d.z = d.z * d.z; d.w = d.w * d.w;
+        if (cis[it] != SENT) *reinterpret_cast<f32x4*>(sq + pl * RR_SQ_STRIDE + 4 * j) = d;
       }
       __syncthreads();
       if (tid < 128) {
