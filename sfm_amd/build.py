@@ -55,7 +55,7 @@ def build_host(force=False):
     build_library()
     common = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith((".hpp", ".cc"))]
     inc = ["-I", HOST, "-I", os.path.join(ROOT, "include")]
-    link = ["-L", LIBDIR, "-lsfm_hip", "-Wl,-rpath," + LIBDIR, "-pthread"]
+    link = ["-L", LIBDIR, "-lsfm_hip", "-Wl,-rpath,$ORIGIN", "-pthread"]
     lib_srcs = [os.path.join(HOST, f) for f in ("hip_brute_force_matcher.cc", "exhaustive_pair_builder.cc", "sfm_data_io.cc")
                 if os.path.exists(os.path.join(HOST, f))]
     for name in ("feature_match_main",):

@@ -1,0 +1,48 @@
+"""CPU-only: the shared library exists, loads, and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "sfm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sfm_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from sfm_amd.binding import EXPORTS
+    assert sorted(EXPORTS) == header_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    import sfm_amd
+    lib = sfm_amd.library()
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_no_silent_cpu_path_without_a_device():
+    import sfm_amd
+    lib = sfm_amd.library()
+    n = ctypes.c_int(0)
+    lib.sfm_hip_device_count(ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(sfm_amd.SfmHipError, match="no HIP device"):
+        sfm_amd.Matcher(0)
+
+
+def test_null_arguments_are_rejected_not_dereferenced():
+    import sfm_amd
+    lib = sfm_amd.library()
+    assert lib.sfm_hip_ctx_create(0, None) != 0
+    assert lib.sfm_hip_sync(None) != 0
+    assert lib.sfm_hip_upload_image(None, 0, None, 0) != 0
+    assert lib.sfm_hip_match_pairs(None, None, 0, 0.8, 1, None, None, None, None, 0) != 0
+    assert lib.sfm_hip_device_count(None) != 0
+    assert b"null" in lib.sfm_hip_last_error(None)

@@ -1,0 +1,116 @@
+"""Host C++ layer: file format, pair builder, interface plumbing (CPU) and the GPU driver."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import oracle
+from sfm_amd import synth
+from sfm_bin import read_sfm_bin, write_sfm_bin
+
+HOST = os.path.join(ROOT, "sfm_amd", "host")
+
+
+@pytest.fixture(scope="session")
+def cpu_driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("host") / "cpu_driver")
+    cmd = ["g++", "-O2", "-std=c++17", "-I", HOST, "-o", exe, os.path.join(ROOT, "tests", "host", "cpu_driver.cc"),
+           os.path.join(HOST, "exhaustive_pair_builder.cc"), os.path.join(HOST, "sfm_data_io.cc"),
+           "-x", "c", "-std=c11", "-ffp-contract=off", os.path.join(ROOT, "oracle", "bf_oracle.c"), "-lm", "-pthread"]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def two_image_set():
+    A, B, _ = synth.make_pair(300, 260, 120, seed=31)
+    images = {3: A, 8: B}
+    kps = {i: synth.keypoints(len(d), i) for i, d in images.items()}
+    return images, kps
+
+
+def check_matches(data, images, cross):
+    assert sorted(data["matches"]) == [(3, 8)]
+    rec = data["matches"][(3, 8)]
+    l, r, _ = oracle.match_pair(images[3], images[8], 0.8, cross)
+    assert rec["li"].tolist() == l.tolist() and rec["ri"].tolist() == r.tolist()
+    # keypoints were (feature index, image id): the observations must carry them over
+    assert rec["lx"].tolist() == l.astype(float).tolist() and set(rec["ly"].tolist()) <= {3.0}
+    assert rec["rx"].tolist() == r.astype(float).tolist() and set(rec["ry"].tolist()) <= {8.0}
+
+
+def test_bin_roundtrip_is_byte_identical(cpu_driver, tmp_path):
+    images, kps = two_image_set()
+    l, r, _ = oracle.match_pair(images[3], images[8], 0.8, True)
+    m = {(3, 8): (kps[3][l], kps[8][r], l, r)}
+    src, dst = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    write_sfm_bin(src, images, kps, m, width=640, height=480)
+    subprocess.run([cpu_driver, "--roundtrip", src, dst], check=True)
+    assert open(src, "rb").read() == open(dst, "rb").read()
+
+
+def test_load_rejects_unknown_extension_and_truncated_files(cpu_driver, tmp_path):
+    images, kps = two_image_set()
+    src = str(tmp_path / "a.bin")
+    write_sfm_bin(src, images, kps)
+    other = str(tmp_path / "a.dat")
+    shutil.copy(src, other)
+    assert subprocess.run([cpu_driver, "--roundtrip", other, str(tmp_path / "o.bin")]).returncode == 4
+    cut = str(tmp_path / "cut.bin")
+    open(cut, "wb").write(open(src, "rb").read()[:5000])
+    assert subprocess.run([cpu_driver, "--roundtrip", cut, str(tmp_path / "o.bin")]).returncode == 4
+    assert subprocess.run([cpu_driver, "--roundtrip", src, str(tmp_path / "o.json")]).returncode == 5
+
+
+@pytest.mark.parametrize("cross", [True, False])
+def test_stage_driver_with_cpu_matcher(cpu_driver, tmp_path, cross):
+    # BASELINE configs[0]: the matching stage on a 2-image set, CPU matcher, no GPU
+    images, kps = two_image_set()
+    path = str(tmp_path / "sfm_data.bin")
+    write_sfm_bin(path, images, kps)
+    out = subprocess.run([cpu_driver, path] + ([] if cross else ["--no-cross-check"]), check=True,
+                         stdout=subprocess.PIPE, text=True).stdout
+    assert "Load Sfm Data Finish" in out and "Need To Match 1 Pairs." in out
+    data = read_sfm_bin(path)
+    assert all(np.array_equal(data["descriptors"][i], images[i]) for i in images)
+    check_matches(data, images, cross)
+
+
+def test_missing_file_is_reported_not_fatal(cpu_driver, tmp_path):
+    path = str(tmp_path / "nothing.bin")
+    p = subprocess.run([cpu_driver, path], stdout=subprocess.PIPE, text=True)
+    assert "Fails" in p.stdout and "Need To Match 0 Pairs." in p.stdout and p.returncode == 0
+    assert read_sfm_bin(path)["matches"] == {}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross", [True, False])
+def test_gpu_stage_driver(tmp_path, cross):
+    exe = os.path.join(ROOT, "sfm_amd", "lib", "feature_match_main")
+    assert os.path.exists(exe), "run python -m sfm_amd.build"
+    images, kps = two_image_set()
+    path = str(tmp_path / "sfm_data.bin")
+    write_sfm_bin(path, images, kps)
+    out = subprocess.run([exe, path] + ([] if cross else ["--no-cross-check"]), check=True,
+                         stdout=subprocess.PIPE, text=True).stdout
+    assert "Need To Match 1 Pairs." in out and "Finish 100.000000 %" in out
+    check_matches(read_sfm_bin(path), images, cross)
+
+
+@pytest.mark.gpu
+def test_gpu_stage_driver_many_images(tmp_path):
+    exe = os.path.join(ROOT, "sfm_amd", "lib", "feature_match_main")
+    imgs = synth.make_image_set(5, 400, 0.5, seed=77)
+    images = {10 * i + 1: im[:n] for i, (im, n) in enumerate(zip(imgs, (400, 250, 129, 400, 1)))}
+    kps = {i: synth.keypoints(len(d), i) for i, d in images.items()}
+    path = str(tmp_path / "sfm_data.bin")
+    write_sfm_bin(path, images, kps)
+    subprocess.run([exe, path], check=True, stdout=subprocess.DEVNULL)
+    data = read_sfm_bin(path)
+    ids = sorted(images)
+    assert sorted(data["matches"]) == [(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]]
+    for (a, b), rec in data["matches"].items():
+        l, r, _ = oracle.match_pair(images[a], images[b], 0.8, True)
+        assert rec["li"].tolist() == l.tolist() and rec["ri"].tolist() == r.tolist(), (a, b)
