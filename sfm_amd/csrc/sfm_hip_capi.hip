@@ -58,6 +58,7 @@ struct sfm_hip_ctx {
   std::vector<hipEvent_t> event_pool;
   sfm_hip_stats stats{};
 
+  int n_cu = 256;                              // compute units of the device (one distance workgroup each)
   size_t batch_bytes_limit = (size_t)6 << 30;  // work space per batch
   int max_pairs_per_batch = 256;
 };
@@ -121,11 +122,11 @@ struct PairPlan {
   size_t bytes() const { return (rowpart_words + colpart_words + best_words) * 4; }
 };
 
-// Split the columns of a pair into chunks so that a batch has enough workgroups
-// to fill the chip (two per CU); fewer chunks mean fewer partial lists.
-void plan_chunks(PairPlan& pl, int row_blocks_in_batch_estimate) {
+// Split the columns of a pair into chunks so that a batch has enough workgroups to fill the
+// chip (the distance kernel runs one workgroup per CU); fewer chunks mean fewer partial lists
+// and less per-workgroup set-up.
+void plan_chunks(PairPlan& pl, int row_blocks_in_batch_estimate, int target_blocks) {
   const int nb_pad = pl.Y->n_pad;
-  const int target_blocks = 512;
   int want = (target_blocks + row_blocks_in_batch_estimate - 1) / std::max(1, row_blocks_in_batch_estimate);
   want = std::max(1, std::min(want, nb_pad / CHUNK_ALIGN));
   int cols = (int)align_up((size_t)(nb_pad + want - 1) / want, CHUNK_ALIGN);
@@ -211,6 +212,7 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
                 std::string("device is ") + prop.gcnArchName + "; this library holds gfx950 code only");
   sfm_hip_ctx* ctx = new sfm_hip_ctx();
   ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&ctx->stage_free[s], hipEventDisableTiming);
@@ -354,7 +356,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     size_t bytes = 0;
     while (count < remaining && count < ctx->max_pairs_per_batch) {
       PairPlan& pl = plans[done + count];
-      plan_chunks(pl, (int)std::min<long>(est_row_blocks, 1 << 20));
+      plan_chunks(pl, (int)std::min<long>(est_row_blocks, 1 << 20), ctx->n_cu);
       if (count > 0 && bytes + pl.bytes() > ctx->batch_bytes_limit) break;
       bytes += pl.bytes();
       count++;
