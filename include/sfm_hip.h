@@ -114,8 +114,12 @@ void* sfm_hip_host_alloc(size_t bytes);
 void sfm_hip_host_free(void* p);
 
 /* Profiling: when enabled, every launch of the distance/top-k kernel is
- * bracketed by HIP events on the context's stream; sfm_hip_get_stats() waits
- * for the stream and folds their durations into distance_ms. */
+ * bracketed by HIP events on the stream it runs on, and consecutive launches
+ * are kept from overlapping (a context alternates between two streams so
+ * that one batch's short tail kernels overlap the next batch's distance
+ * kernel; with timing on, distance kernels additionally wait for each other,
+ * which costs a few percent of throughput).  sfm_hip_get_stats() waits for
+ * the queued work and folds the durations into distance_ms. */
 int sfm_hip_set_profiling(sfm_hip_ctx* ctx, int enabled);
 int sfm_hip_get_stats(sfm_hip_ctx* ctx, sfm_hip_stats* out);
 int sfm_hip_reset_stats(sfm_hip_ctx* ctx);

@@ -141,15 +141,20 @@ class Matcher:
         return n.value
 
     def _outputs(self, n_pairs, stride):
+        # Two sets, used in turn: the library overlaps consecutive calls, and two calls in
+        # flight must not write the same host buffers.
         shape = (n_pairs, stride)
         if self._bufs is None or self._bufs_shape != shape:
             if self._bufs:
+                self.sync()
                 for b in self._bufs:
                     b.free()
-            self._bufs = [_Pinned(self._lib, (n_pairs,), np.int32), _Pinned(self._lib, shape, np.int32),
-                          _Pinned(self._lib, shape, np.int32), _Pinned(self._lib, shape, np.float32)]
+            self._bufs = [_Pinned(self._lib, s, t) for _ in range(2)
+                          for s, t in (((n_pairs,), np.int32), (shape, np.int32), (shape, np.int32), (shape, np.float32))]
             self._bufs_shape = shape
-        return self._bufs
+            self._turn = 0
+        self._turn ^= 1
+        return self._bufs[4 * self._turn:4 * self._turn + 4]
 
     def match_pairs_async(self, pairs, ratio=0.8, cross_check=True, stride=None):
         """Queue the pairs; returns the pinned output arrays (valid after sync())."""

@@ -305,8 +305,12 @@ __device__ __forceinline__ void tile_pair(const float (&a0)[64], const float (&a
   pair_steps<TOFF, CT % 3, (CT < 3)>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X);
 
   uint32_t cl0 = SENT, cl1 = SENT, cl2 = SENT;
+#ifdef SFM_ABLATE_FOLD
+  asm volatile("" ::"v"(acc0), "v"(acc1));   // diagnostic build: accumulators stay live, lists untouched
+#else
   tile_fold<0>(acc0, tv, L0, cl0, cl1, cl2);
   tile_fold<1>(acc1, tv, L1, cl0, cl1, cl2);
+#endif
   cl0 |= lowc;
   cl1 |= lowc;
   cl2 |= lowc;
@@ -426,7 +430,9 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 #pragma unroll
     for (int ct = 0; ct < 4; ct++) bn[ct] = h == 0 ? 1.0f : nbn[ct];
     if (gg + 1 < nstages) {
+#ifndef SFM_ABLATE_GLDS
       stage_load(ybase + (size_t)(gg + 1) * SN * DIM, smem + (u ^ 1) * LDS_STAGE_BYTES, w, l);
+#endif
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) nbn[ct] = ynp[(gg + 1) * SN + 32 * ct];
     }

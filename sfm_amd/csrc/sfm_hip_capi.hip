@@ -37,21 +37,32 @@ struct TimedLaunch {
 
 }  // namespace
 
-struct sfm_hip_ctx {
-  int device = 0;
+// A lane = one stream with its own work space.  Consecutive batches alternate between the
+// lanes, so that the next batch's distance kernel starts while the previous batch's short
+// kernels (re-rank, compaction) are still draining; nothing is shared between two batches.
+struct Lane {
   hipStream_t stream = nullptr;
-  std::map<int64_t, Image> images;
-  std::string last_error;
-
   // grow-only device work space
   DevBuf tables_dev, rowpart, colpart, best, out_dev;
-  unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
   std::vector<char> tables_shadow;               // what tables_dev currently holds
   // pinned staging for the per-batch tables, two slots
   void* stage_host[2] = {nullptr, nullptr};
   size_t stage_bytes[2] = {0, 0};
   hipEvent_t stage_free[2] = {nullptr, nullptr};
   int stage_slot = 0;
+  hipEvent_t distance_done = nullptr;   // recorded after this lane's latest distance kernel
+  bool distance_recorded = false;
+};
+
+constexpr int N_LANES = 2;
+
+struct sfm_hip_ctx {
+  int device = 0;
+  Lane lanes[N_LANES];
+  int next_lane = 0;
+  std::map<int64_t, Image> images;
+  std::string last_error;
+  unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
 
   bool profiling = false;
   std::vector<TimedLaunch> timed;
@@ -79,10 +90,15 @@ int fail(sfm_hip_ctx* ctx, int code, const std::string& msg) {
     }                                                                                      \
   } while (0)
 
-int ensure(sfm_hip_ctx* ctx, DevBuf& b, size_t bytes) {
+int sync_all(sfm_hip_ctx* ctx) {
+  for (Lane& l : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+  return SFM_HIP_OK;
+}
+
+int ensure(sfm_hip_ctx* ctx, Lane& L, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes) return SFM_HIP_OK;
-  // the old buffer may still be in use by queued work
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // the old buffer may still be in use by work queued on its lane
+  HIP_TRY(ctx, hipStreamSynchronize(L.stream));
   if (b.p) HIP_TRY(ctx, hipFree(b.p));
   b.p = nullptr;
   b.bytes = 0;
@@ -96,13 +112,13 @@ int ensure(sfm_hip_ctx* ctx, DevBuf& b, size_t bytes) {
   return SFM_HIP_OK;
 }
 
-int ensure_stage(sfm_hip_ctx* ctx, int slot, size_t bytes) {
-  if (ctx->stage_bytes[slot] >= bytes) return SFM_HIP_OK;
-  if (ctx->stage_host[slot]) HIP_TRY(ctx, hipHostFree(ctx->stage_host[slot]));
-  ctx->stage_host[slot] = nullptr;
-  ctx->stage_bytes[slot] = 0;
-  HIP_TRY(ctx, hipHostMalloc(&ctx->stage_host[slot], bytes * 2, hipHostMallocDefault));
-  ctx->stage_bytes[slot] = bytes * 2;
+int ensure_stage(sfm_hip_ctx* ctx, Lane& L, int slot, size_t bytes) {
+  if (L.stage_bytes[slot] >= bytes) return SFM_HIP_OK;
+  if (L.stage_host[slot]) HIP_TRY(ctx, hipHostFree(L.stage_host[slot]));
+  L.stage_host[slot] = nullptr;
+  L.stage_bytes[slot] = 0;
+  HIP_TRY(ctx, hipHostMalloc(&L.stage_host[slot], bytes * 2, hipHostMallocDefault));
+  L.stage_bytes[slot] = bytes * 2;
   return SFM_HIP_OK;
 }
 
@@ -214,13 +230,16 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&ctx->stage_free[s], hipEventDisableTiming);
+  for (Lane& l : ctx->lanes) {
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+    for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&l.stage_free[s], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.distance_done, hipEventDisableTiming);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->rescanned_dev, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(ctx->rescanned_dev, 0, sizeof(unsigned long long));
   if (e != hipSuccess) {
     std::string msg = std::string("context set-up: ") + hipGetErrorString(e);
-    delete ctx;
+    sfm_hip_ctx_destroy(ctx);
     return fail(nullptr, SFM_HIP_ERR_HIP, msg);
   }
   *out_ctx = ctx;
@@ -230,21 +249,25 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
 void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (Lane& l : ctx->lanes)
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
   for (auto& kv : ctx->images) free_image(kv.second);
-  for (DevBuf* b : {&ctx->tables_dev, &ctx->rowpart, &ctx->colpart, &ctx->best, &ctx->out_dev})
-    if (b->p) (void)hipFree(b->p);
-  if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
-  for (int s = 0; s < 2; s++) {
-    if (ctx->stage_host[s]) (void)hipHostFree(ctx->stage_host[s]);
-    if (ctx->stage_free[s]) (void)hipEventDestroy(ctx->stage_free[s]);
+  for (Lane& l : ctx->lanes) {
+    for (DevBuf* b : {&l.tables_dev, &l.rowpart, &l.colpart, &l.best, &l.out_dev})
+      if (b->p) (void)hipFree(b->p);
+    for (int s = 0; s < 2; s++) {
+      if (l.stage_host[s]) (void)hipHostFree(l.stage_host[s]);
+      if (l.stage_free[s]) (void)hipEventDestroy(l.stage_free[s]);
+    }
+    if (l.distance_done) (void)hipEventDestroy(l.distance_done);
+    if (l.stream) (void)hipStreamDestroy(l.stream);
   }
+  if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
   for (auto& t : ctx->timed) {
     (void)hipEventDestroy(t.start);
     (void)hipEventDestroy(t.stop);
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -256,7 +279,8 @@ int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descri
   if (n > 0 && !descriptors) return fail(ctx, SFM_HIP_ERR_INVALID, "descriptors is null");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // queued work may still read the image being replaced
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = sync_all(ctx)) return rc;
+  hipStream_t up = ctx->lanes[0].stream;
   auto it = ctx->images.find(image_id);
   if (it != ctx->images.end()) {
     free_image(it->second);
@@ -273,15 +297,15 @@ int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descri
     return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc norms: ") + hipGetErrorString(e));
   }
   e = hipSuccess;
-  if (n > 0) e = hipMemcpyAsync(im.d, descriptors, (size_t)n * row_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (n > 0) e = hipMemcpyAsync(im.d, descriptors, (size_t)n * row_bytes, hipMemcpyHostToDevice, up);
   if (e == hipSuccess && im.n_pad > n)
-    e = hipMemsetAsync(im.d + (size_t)n * DIM, 0, (size_t)(im.n_pad - n) * row_bytes, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(im.norms + im.n_pad, 0, sizeof(float), ctx->stream);
+    e = hipMemsetAsync(im.d + (size_t)n * DIM, 0, (size_t)(im.n_pad - n) * row_bytes, up);
+  if (e == hipSuccess) e = hipMemsetAsync(im.norms + im.n_pad, 0, sizeof(float), up);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_norms, dim3((im.n_pad + 3) / 4), dim3(256), 0, ctx->stream, im.d, im.norms, n, im.n_pad);
+    hipLaunchKernelGGL(k_norms, dim3((im.n_pad + 3) / 4), dim3(256), 0, up, im.d, im.norms, n, im.n_pad);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(up);
   if (e != hipSuccess) {
     free_image(im);
     return fail(ctx, SFM_HIP_ERR_HIP, std::string("image upload: ") + hipGetErrorString(e));
@@ -295,7 +319,7 @@ int sfm_hip_drop_image(sfm_hip_ctx* ctx, int64_t image_id) {
   auto it = ctx->images.find(image_id);
   if (it == ctx->images.end()) return fail(ctx, SFM_HIP_ERR_INVALID, "unknown image id " + std::to_string(image_id));
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = sync_all(ctx)) return rc;
   free_image(it->second);
   ctx->images.erase(it);
   return SFM_HIP_OK;
@@ -304,7 +328,7 @@ int sfm_hip_drop_image(sfm_hip_ctx* ctx, int64_t image_id) {
 int sfm_hip_drop_all_images(sfm_hip_ctx* ctx) {
   if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = sync_all(ctx)) return rc;
   for (auto& kv : ctx->images) free_image(kv.second);
   ctx->images.clear();
   return SFM_HIP_OK;
@@ -362,6 +386,9 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       count++;
     }
 
+    Lane& L = ctx->lanes[ctx->next_lane];
+    ctx->next_lane = (ctx->next_lane + 1) % N_LANES;
+
     // ---- lay out the work space and build the tables
     size_t rowpart_words = 0, colpart_words = 0, best_words = 0, n_blocks = 0, n_queries = 0;
     int max_na = 0, max_nb = 0;
@@ -378,10 +405,10 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     int rc;
     const size_t pairs_bytes = align_up(sizeof(PairDev) * count, 256);
     const size_t table_bytes = pairs_bytes + sizeof(BlockDev) * n_blocks;
-    if ((rc = ensure(ctx, ctx->tables_dev, table_bytes))) return rc;
-    if ((rc = ensure(ctx, ctx->rowpart, rowpart_words * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->colpart, colpart_words * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->best, best_words * 4))) return rc;
+    if ((rc = ensure(ctx, L, L.tables_dev, table_bytes))) return rc;
+    if ((rc = ensure(ctx, L, L.rowpart, rowpart_words * 4))) return rc;
+    if ((rc = ensure(ctx, L, L.colpart, colpart_words * 4))) return rc;
+    if ((rc = ensure(ctx, L, L.best, best_words * 4))) return rc;
 
     // Outputs: kernels write straight into the caller's buffers when those are
     // pinned host memory; otherwise into a device staging area that is copied back.
@@ -394,9 +421,9 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     const bool direct = k_counts && k_lhs && k_rhs && (k_dist || !out_dist);
     if (!direct || !out_dist) {
       // counts | lhs | rhs | dist
-      if ((rc = ensure(ctx, ctx->out_dev, align_up((size_t)count * 4, 256) + 3 * align_up(out_words * 4, 256) + 256)))
+      if ((rc = ensure(ctx, L, L.out_dev, align_up((size_t)count * 4, 256) + 3 * align_up(out_words * 4, 256) + 256)))
         return rc;
-      char* ob = (char*)ctx->out_dev.p;
+      char* ob = (char*)L.out_dev.p;
       int32_t* d_counts = (int32_t*)ob;
       ob += align_up((size_t)count * 4, 256);
       int32_t* d_lhs = (int32_t*)ob;
@@ -414,17 +441,17 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       }
     }
 
-    const int slot = ctx->stage_slot;
-    ctx->stage_slot ^= 1;
-    HIP_TRY(ctx, hipEventSynchronize(ctx->stage_free[slot]));
-    if ((rc = ensure_stage(ctx, slot, table_bytes))) return rc;
-    std::memset(ctx->stage_host[slot], 0, table_bytes);
-    PairDev* hp = reinterpret_cast<PairDev*>(ctx->stage_host[slot]);
-    BlockDev* hb = reinterpret_cast<BlockDev*>((char*)ctx->stage_host[slot] + pairs_bytes);
+    const int slot = L.stage_slot;
+    L.stage_slot ^= 1;
+    HIP_TRY(ctx, hipEventSynchronize(L.stage_free[slot]));
+    if ((rc = ensure_stage(ctx, L, slot, table_bytes))) return rc;
+    std::memset(L.stage_host[slot], 0, table_bytes);
+    PairDev* hp = reinterpret_cast<PairDev*>(L.stage_host[slot]);
+    BlockDev* hb = reinterpret_cast<BlockDev*>((char*)L.stage_host[slot] + pairs_bytes);
 
-    uint32_t* rp = (uint32_t*)ctx->rowpart.p;
-    uint32_t* cp = (uint32_t*)ctx->colpart.p;
-    uint32_t* bp = (uint32_t*)ctx->best.p;
+    uint32_t* rp = (uint32_t*)L.rowpart.p;
+    uint32_t* cp = (uint32_t*)L.colpart.p;
+    uint32_t* bp = (uint32_t*)L.best.p;
     size_t nb_i = 0;
     double flop = 0.0;
     for (int k = 0; k < count; k++) {
@@ -470,20 +497,27 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     }
 
     // ---- queue the batch
-    hipStream_t st = ctx->stream;
+    hipStream_t st = L.stream;
     // The device keeps the previous batch's tables; identical tables (the same
     // pairs matched again) need no new upload.
-    const bool same_tables = ctx->tables_shadow.size() == table_bytes &&
-                             std::memcmp(ctx->tables_shadow.data(), ctx->stage_host[slot], table_bytes) == 0;
+    const bool same_tables = L.tables_shadow.size() == table_bytes &&
+                             std::memcmp(L.tables_shadow.data(), L.stage_host[slot], table_bytes) == 0;
     if (!same_tables) {
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->tables_dev.p, ctx->stage_host[slot], table_bytes, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipEventRecord(ctx->stage_free[slot], st));
-      ctx->tables_shadow.assign((char*)ctx->stage_host[slot], (char*)ctx->stage_host[slot] + table_bytes);
+      HIP_TRY(ctx, hipMemcpyAsync(L.tables_dev.p, L.stage_host[slot], table_bytes, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipEventRecord(L.stage_free[slot], st));
+      L.tables_shadow.assign((char*)L.stage_host[slot], (char*)L.stage_host[slot] + table_bytes);
     }
 
-    const PairDev* dp = (const PairDev*)ctx->tables_dev.p;
-    const BlockDev* db = (const BlockDev*)((const char*)ctx->tables_dev.p + pairs_bytes);
+    const PairDev* dp = (const PairDev*)L.tables_dev.p;
+    const BlockDev* db = (const BlockDev*)((const char*)L.tables_dev.p + pairs_bytes);
     if (n_blocks) {
+      // While per-launch timing is on, a distance kernel waits for the other lane's previous
+      // one: a launch duration only means something when launches do not share the chip.
+      // (Without timing they are left free: the next launch's workgroups then take over compute
+      // units one by one as the previous launch's workgroups finish, which is worth a few percent.)
+      if (ctx->profiling)
+        for (Lane& o : ctx->lanes)
+          if (&o != &L && o.distance_recorded) HIP_TRY(ctx, hipStreamWaitEvent(st, o.distance_done, 0));
       TimedLaunch tl{};
       if (ctx->profiling) {
         tl.start = get_event(ctx);
@@ -497,6 +531,8 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
         HIP_TRY(ctx, hipEventRecord(tl.stop, st));
         ctx->timed.push_back(tl);
       }
+      HIP_TRY(ctx, hipEventRecord(L.distance_done, st));
+      L.distance_recorded = true;
     }
     // Pairs with an empty image still go through the re-rank step: with no
     // candidates every query comes out unmatched, as in the reference.  Their
@@ -536,8 +572,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
 int sfm_hip_sync(sfm_hip_ctx* ctx) {
   if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return SFM_HIP_OK;
+  return sync_all(ctx);
 }
 
 void* sfm_hip_host_alloc(size_t bytes) {
