@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pairs-per-step", type=int, default=1,
                     help="pairs handed to one sfm_hip_match_pairs call (default 1: the headline configuration)")
+    ap.add_argument("--untimed-pass", action="store_true",
+                    help="after the timed region, run the same K steps once more without per-launch kernel "
+                         "timing and report that rate as an extra field")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not bracket the distance kernel with HIP events in the timed region")
     args = ap.parse_args()
@@ -90,11 +93,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    m.set_profiling(not args.no_profile_events)
     for _ in range(args.warmup):
         m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
     m.sync()
     m.reset_stats()
-    m.set_profiling(not args.no_profile_events)
 
     barrier()
     t0 = time.perf_counter()
@@ -106,10 +109,10 @@ def main():
 
     st = m.stats()
     m.set_profiling(False)
-    # extra, untimed-by-contract information: the same K steps without per-launch kernel timing
+    # extra information outside the timed region: the same K steps without per-launch kernel timing
     # (the library then lets consecutive distance kernels overlap at their edges)
     free_rate = None
-    if not args.no_profile_events:
+    if args.untimed_pass:
         m.sync()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -130,11 +133,18 @@ def main():
         value = total_pairs / elapsed
         flop_per_launch = 2.0 * N_FEATURES * N_FEATURES * 128
         roof = None
+        # HBM-side bytes per launch of the distance kernel come from a separate hardware-counter
+        # run of this same workload (tools/collect_profiles.sh), kept beside the profiles.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "distance_kernel_traffic.json")
+        if os.path.exists(tpath) and args.pairs_per_step == 1:
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("traffic_bytes_per_launch")
         if st["distance_launches"]:
             avg_ms = st["distance_ms"] / st["distance_launches"]
             achieved = st["distance_flop"] / st["distance_launches"] / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                     "kernel": "k_distance_topk", "avg_launch_ms": avg_ms, "flop_per_launch": flop_per_launch * args.pairs_per_step}
         planted_found = len(set(zip(got[0].tolist(), got[1].tolist())) & set(map(tuple, truth.tolist())))
         line = {
