@@ -58,7 +58,7 @@ def build_host(force=False):
     link = ["-L", LIBDIR, "-lsfm_hip", "-Wl,-rpath,$ORIGIN", "-pthread"]
     lib_srcs = [os.path.join(HOST, f) for f in ("hip_brute_force_matcher.cc", "exhaustive_pair_builder.cc", "sfm_data_io.cc")
                 if os.path.exists(os.path.join(HOST, f))]
-    for name in ("feature_match_main",):
+    for name in ("feature_match_main", "match_set_bench"):
         src = os.path.join(HOST, name + ".cc")
         if not os.path.exists(src):
             continue

@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -13,8 +15,28 @@
 
 namespace {
 
-struct PairResult {
-  std::vector<int32_t> lhs, rhs;
+// Everything a worker needs for one pair, looked up once on the calling thread so that workers
+// never touch the maps' structure.
+struct PairJob {
+  Pair pair;
+  const Descriptors* first;
+  const Descriptors* second;
+  const std::vector<KeyPoint>* kl;
+  const std::vector<KeyPoint>* kr;
+  Matches* out;
+};
+
+struct Progress {
+  std::mutex mu;
+  int done = 0;
+  int total = 0;
+  bool print = true;
+  // brute_force_matcher.cc:85: one line per finished pair
+  void pair_finished() {
+    if (!print) return;
+    std::lock_guard<std::mutex> lock(mu);
+    std::printf("Finish %f %%\n", 100.0 * ++done / total);
+  }
 };
 
 [[noreturn]] void fail(sfm_hip_ctx* ctx, const char* what) {
@@ -22,60 +44,96 @@ struct PairResult {
   throw std::runtime_error(msg);
 }
 
-// One GPU: upload the images its pairs touch, match its slice of the pair list in sub-batches.
-void run_device(int device, const std::vector<Pair>& pairs, size_t lo, size_t hi, SfMData& sfm_data, double ratio,
-                bool cross, std::vector<PairResult>& results) {
+// brute_force_matcher.cc:36-37: the Match records are built on the host, observations never
+// leave it.
+void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int32_t n) {
+  Matches& out = *job.out;
+  out.reserve((size_t)n);
+  for (int32_t m = 0; m < n; m++) {
+    const IndexT i = lhs[m], j = rhs[m];
+    // 'struct': inside the matcher's translation unit the bare name also names a member function
+    struct Match rec{ToObservation(job.kl->at((size_t)i)), ToObservation(job.kr->at((size_t)j)), i, j};
+    out.push_back(rec);
+  }
+}
+
+// One GPU: upload the images its pairs touch, then match its slice of the pair list in batches.
+// Two sets of pinned result buffers alternate, so the GPU works on batch b while this thread
+// turns batch b-1 into Match records.
+void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t hi, double ratio, bool cross,
+                Progress& progress) {
   sfm_hip_ctx* ctx = nullptr;
   if (sfm_hip_ctx_create(device, &ctx) != SFM_HIP_OK) fail(nullptr, "sfm_hip_ctx_create");
   struct Guard {
     sfm_hip_ctx* c;
     std::vector<void*> pinned;
     ~Guard() {
+      sfm_hip_sync(c);   // nothing may still be writing into the pinned buffers
       for (void* p : pinned) sfm_hip_host_free(p);
       sfm_hip_ctx_destroy(c);
     }
   } guard{ctx, {}};
 
-  std::set<IndexT> ids;
+  std::map<IndexT, const Descriptors*> images;
   int64_t stride = 1;
   for (size_t p = lo; p < hi; p++) {
-    ids.insert(pairs[p].first);
-    ids.insert(pairs[p].second);
+    images[jobs[p].pair.first] = jobs[p].first;
+    images[jobs[p].pair.second] = jobs[p].second;
   }
-  for (IndexT id : ids) {
-    const Descriptors& d = sfm_data.descriptors.at(id);
-    if (sfm_hip_upload_image(ctx, id, d.data(), (int32_t)d.size()) != SFM_HIP_OK) fail(ctx, "sfm_hip_upload_image");
-    stride = std::max<int64_t>(stride, (int64_t)d.size());
+  for (const auto& [id, d] : images) {
+    if (sfm_hip_upload_image(ctx, id, d->data(), (int32_t)d->size()) != SFM_HIP_OK)
+      fail(ctx, "sfm_hip_upload_image");
+    stride = std::max<int64_t>(stride, (int64_t)d->size());
   }
 
-  // sub-batches bound the pinned result buffers (stride ints per pair and array)
-  const size_t batch = std::max<size_t>(1, std::min<size_t>(256, ((size_t)64 << 20) / ((size_t)stride * 8)));
+  // batches bound the pinned result buffers (two arrays of stride ints per pair, two sets)
+  const size_t batch = std::max<size_t>(1, std::min<size_t>(64, ((size_t)32 << 20) / ((size_t)stride * 8)));
   auto pin = [&](size_t bytes) {
     void* p = sfm_hip_host_alloc(bytes);
     if (!p) throw std::runtime_error("HipBruteForceMatcher: pinned host allocation failed");
     guard.pinned.push_back(p);
     return p;
   };
-  int32_t* counts = (int32_t*)pin(batch * sizeof(int32_t));
-  int32_t* out_l = (int32_t*)pin(batch * (size_t)stride * sizeof(int32_t));
-  int32_t* out_r = (int32_t*)pin(batch * (size_t)stride * sizeof(int32_t));
+  struct Set {
+    int32_t *counts, *lhs, *rhs;
+  } sets[2];
+  for (Set& s : sets) {
+    s.counts = (int32_t*)pin(batch * sizeof(int32_t));
+    s.lhs = (int32_t*)pin(batch * (size_t)stride * sizeof(int32_t));
+    s.rhs = (int32_t*)pin(batch * (size_t)stride * sizeof(int32_t));
+  }
   std::vector<int64_t> flat(2 * batch);
-  for (size_t b0 = lo; b0 < hi; b0 += batch) {
+
+  auto submit = [&](size_t b0, const Set& s) {
     const size_t n = std::min(batch, hi - b0);
     for (size_t k = 0; k < n; k++) {
-      flat[2 * k] = pairs[b0 + k].first;
-      flat[2 * k + 1] = pairs[b0 + k].second;
+      flat[2 * k] = jobs[b0 + k].pair.first;
+      flat[2 * k + 1] = jobs[b0 + k].pair.second;
     }
-    if (sfm_hip_match_pairs(ctx, flat.data(), (int32_t)n, ratio, cross ? 1 : 0, counts, out_l, out_r, nullptr,
+    if (sfm_hip_match_pairs(ctx, flat.data(), (int32_t)n, ratio, cross ? 1 : 0, s.counts, s.lhs, s.rhs, nullptr,
                             stride) != SFM_HIP_OK)
       fail(ctx, "sfm_hip_match_pairs");
-    if (sfm_hip_sync(ctx) != SFM_HIP_OK) fail(ctx, "sfm_hip_sync");
+  };
+  auto collect = [&](size_t b0, const Set& s) {
+    const size_t n = std::min(batch, hi - b0);
     for (size_t k = 0; k < n; k++) {
-      PairResult& r = results[b0 + k];
-      r.lhs.assign(out_l + k * stride, out_l + k * stride + counts[k]);
-      r.rhs.assign(out_r + k * stride, out_r + k * stride + counts[k]);
+      materialise(jobs[b0 + k], s.lhs + k * stride, s.rhs + k * stride, s.counts[k]);
+      progress.pair_finished();
     }
+  };
+
+  size_t which = 0;
+  size_t prev = lo;
+  submit(lo, sets[which]);
+  for (size_t b0 = lo + batch; b0 < hi; b0 += batch) {
+    if (sfm_hip_sync(ctx) != SFM_HIP_OK) fail(ctx, "sfm_hip_sync");   // batch 'prev' is complete
+    submit(b0, sets[which ^ 1]);
+    collect(prev, sets[which]);
+    prev = b0;
+    which ^= 1;
   }
+  if (sfm_hip_sync(ctx) != SFM_HIP_OK) fail(ctx, "sfm_hip_sync");
+  collect(prev, sets[which]);
 }
 
 }  // namespace
@@ -100,20 +158,29 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
     want = env ? std::atoi(env) : visible;
     if (want <= 0) want = visible;
   }
-  const std::vector<Pair> list(pairs.begin(), pairs.end());   // std::set order: lexicographic
-  const int n_dev = (int)std::min<size_t>((size_t)std::min(want, visible), list.size());
+  // std::set order: lexicographic.  The maps are not modified from here on, so the pointers
+  // taken now stay valid while the workers run, and each worker writes only its own pairs' lists.
+  std::vector<PairJob> jobs;
+  jobs.reserve(pairs.size());
+  for (const Pair& pair : pairs)
+    jobs.push_back(PairJob{pair, &sfm_data.descriptors.at(pair.first), &sfm_data.descriptors.at(pair.second),
+                           &sfm_data.key_points.at(pair.first), &sfm_data.key_points.at(pair.second),
+                           &sfm_data.matches.at(pair)});
+  const int n_dev = (int)std::min<size_t>((size_t)std::min(want, visible), jobs.size());
 
   // static contiguous shards, sizes differ by at most one
-  std::vector<PairResult> results(list.size());
+  Progress progress;
+  progress.total = (int)jobs.size();
+  progress.print = print_progress_;
   std::vector<std::thread> workers;
   std::vector<std::exception_ptr> errors((size_t)n_dev);
-  const size_t base = list.size() / n_dev, extra = list.size() % n_dev;
+  const size_t base = jobs.size() / n_dev, extra = jobs.size() % n_dev;
   size_t lo = 0;
   for (int d = 0; d < n_dev; d++) {
     const size_t hi = lo + base + ((size_t)d < extra ? 1 : 0);
     workers.emplace_back([&, d, lo, hi] {
       try {
-        run_device(d, list, lo, hi, sfm_data, ratio_, is_cross_valid, results);
+        run_device(d, jobs, lo, hi, ratio_, is_cross_valid, progress);
       } catch (...) {
         errors[(size_t)d] = std::current_exception();
       }
@@ -123,22 +190,4 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
   for (auto& t : workers) t.join();
   for (auto& e : errors)
     if (e) std::rethrow_exception(e);
-
-  // brute_force_matcher.cc:36-37, 80-85: build the Match records on the host (observations never
-  // leave it) and report progress per pair as the reference does
-  int count = 0;
-  const int total = (int)list.size();
-  for (size_t p = 0; p < list.size(); p++) {
-    const std::vector<KeyPoint>& kl = sfm_data.key_points.at(list[p].first);
-    const std::vector<KeyPoint>& kr = sfm_data.key_points.at(list[p].second);
-    Matches& out = sfm_data.matches[list[p]];
-    out.reserve(results[p].lhs.size());
-    for (size_t m = 0; m < results[p].lhs.size(); m++) {
-      const IndexT i = results[p].lhs[m], j = results[p].rhs[m];
-      // 'struct': inside this member function the bare name means the function
-      struct Match rec{ToObservation(kl.at((size_t)i)), ToObservation(kr.at((size_t)j)), i, j};
-      out.push_back(rec);
-    }
-    if (print_progress_) std::printf("Finish %f %%\n", 100.0 * ++count / total);
-  }
 }
