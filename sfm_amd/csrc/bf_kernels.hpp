@@ -36,11 +36,17 @@ constexpr int SN = 128;              // columns of S per LDS stage (4 tiles of 3
 constexpr int CHUNK_ALIGN = 2 * SN;  // chunks hold an even number of stages
 constexpr int IMG_PAD = 256;         // images are padded to a multiple of this many rows
 constexpr uint32_t SENT = 0xFFFFFFFFu;   // "empty" key, larger than every real key
+// A key is the bit pattern of a computed squared distance with the sign bit cleared and the low
+// mantissa bits replaced by a local index.  Rounding can leave a distance that is really ~0 slightly
+// negative; clearing the sign turns it into an equally tiny positive key, so it still sorts first
+// and unsigned integer order equals numeric order for every key.
 constexpr int ROW_IDX_BITS = 9;      // row lists: low bits = 32-column tile number inside the chunk
-constexpr uint32_t ROW_MASK = ~((1u << ROW_IDX_BITS) - 1u);
+constexpr uint32_t ROW_LOW = (1u << ROW_IDX_BITS) - 1u;
+constexpr uint32_t ROW_MASK = 0x7FFFFFFFu & ~ROW_LOW;
 constexpr int MAX_CHUNK_COLS = 32 << ROW_IDX_BITS;   // 16384
 constexpr int COL_IDX_BITS = 8;      // column lists: low bits = row inside the 256-row block (permuted)
-constexpr uint32_t COL_MASK = ~((1u << COL_IDX_BITS) - 1u);
+constexpr uint32_t COL_LOW = (1u << COL_IDX_BITS) - 1u;
+constexpr uint32_t COL_MASK = 0x7FFFFFFFu & ~COL_LOW;
 constexpr float PAD_NORM = 1e30f;    // squared norm given to padding rows: never a near neighbour
 constexpr int NCAND = 4;             // candidates re-ranked exactly per query
 constexpr int ROWPART_FIELDS = 2 * NCAND + 1;  // keys, column indices, bound key
@@ -153,19 +159,20 @@ __global__ __launch_bounds__(256) void k_norms(const float* __restrict__ x, floa
 // 3-entry list per row over the columns it sees (c, c+32, ...) and the lists are
 // merged once, at the end of the chunk.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void stage_load(const float* __restrict__ ysrc, char* ldsbuf, int w, int l) {
-  // Wave w fills rows 32w .. 32w+31 of the stage: 16 instructions of 1 KiB (2 rows) each.
-  const int pc = l & 31;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int q = w * 16 + i;
-    const int R = 2 * q + (l >> 5);
-    const int lc = pc ^ (R & 15);
-    const float* src = ysrc + (size_t)R * DIM + lc * 4;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)src,
-        (__attribute__((address_space(3))) void*)(ldsbuf + q * 1024), 16, 0, 0);
-  }
+// Wave w fills rows 32w .. 32w+31 of a stage: 16 LDS-DMA instructions of 1 KiB (2 rows) each.
+// Addressing is a buffer descriptor over the chunk's columns + a per-lane byte offset (voff: the
+// swizzled position inside a 1 KiB piece, which repeats every 8 pieces) + a scalar offset per
+// piece, so issuing a stage costs no vector instructions.
+template <int I>
+__device__ __forceinline__ void stage_load_piece(__amdgpu_buffer_rsrc_t ysrc, char* ldsbuf, int w,
+                                                 const uint32_t (&voff)[8], uint32_t sbase) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrc, (__attribute__((address_space(3))) void*)(ldsbuf + (w * 16 + I) * 1024),
+                                           16, voff[I & 7], sbase + I * 1024, 0, 0);
+}
+template <int... I>
+__device__ __forceinline__ void stage_load(std::integer_sequence<int, I...>, __amdgpu_buffer_rsrc_t ysrc, char* ldsbuf,
+                                           int w, const uint32_t (&voff)[8], uint32_t sbase) {
+  (stage_load_piece<I>(ysrc, ldsbuf, w, voff, sbase), ...);
 }
 
 // Running top-5 of (key, index) pairs, ascending by key; branch-free insertion.
@@ -202,12 +209,6 @@ __device__ __forceinline__ uint32_t other_half(uint32_t v) {
   // operands equal to v the second result holds v's upper half in every lane below 32.
   auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
   return r[1];
-}
-
-// Bits of max(x, 0) for a finite x: negative floats are negative as integers.
-__device__ __forceinline__ uint32_t clamp_bits(float x) {
-  const int32_t i = (int32_t)__float_as_uint(x);
-  return (uint32_t)(i > 0 ? i : 0);
 }
 
 // One 16-byte LDS read whose completion the compiler does not track: the caller
@@ -279,7 +280,7 @@ __device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLi
                                           uint32_t& cl2) {
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
-    const uint32_t gb = clamp_bits(acc[reg]);
+    const uint32_t gb = __float_as_uint(acc[reg]);
     insert3(L.r0[reg], L.r1[reg], L.r2[reg], (gb & ROW_MASK) | tv);
     insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)(RT * 32 + reg));
   }
@@ -330,18 +331,23 @@ __device__ __forceinline__ void tile_pair(const float (&a0)[64], const float (&a
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// Merge the four waves' lists of 32 columns of a finished stage (one lane each) and store them.
-__device__ __forceinline__ void stage_columns_out(const uint32_t* cb, int ct, int c, uint32_t* dst, size_t nb_pad) {
-  uint32_t k0 = cb[((0 * 4 + ct) * 3 + 0) * 32 + c];
-  uint32_t k1 = cb[((0 * 4 + ct) * 3 + 1) * 32 + c];
-  uint32_t k2 = cb[((0 * 4 + ct) * 3 + 2) * 32 + c];
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// Merge the four waves' lists of one column of a finished stage and store them.  cbaddr is the
+// LDS byte address of this lane's entry of wave 0, list entry 0; it is made opaque to the
+// optimizer so that the twelve reads stay "one register + immediate offset".
+__device__ __forceinline__ void stage_columns_out(uint32_t cbaddr, __amdgpu_buffer_rsrc_t dst, uint32_t voff,
+                                                  uint32_t soff, uint32_t plane_bytes) {
+  asm volatile("" : "+v"(cbaddr));
+  const lds_u32* cb = (const lds_u32*)cbaddr;
+  uint32_t k0 = cb[0], k1 = cb[32], k2 = cb[64];
 #pragma unroll
   for (int wv = 1; wv < 4; wv++)
 #pragma unroll
-    for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[((wv * 4 + ct) * 3 + k) * 32 + c]);
-  dst[0] = k0;
-  dst[nb_pad] = k1;
-  dst[2 * nb_pad] = k2;
+    for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[wv * 4 * 3 * 32 + k * 32]);
+  __builtin_amdgcn_raw_buffer_store_b32(k0, dst, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(k1, dst, voff, soff + plane_bytes, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(k2, dst, voff, soff + 2 * plane_bytes, 0);
 }
 
 #ifdef SFM_K1_STAMPS
@@ -369,11 +375,19 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 
   uint32_t* colbuf = reinterpret_cast<uint32_t*>(smem + LDS_OFF_COLBUF);
 
-  const float* ybase = P.y + (size_t)blk.col0 * DIM;
   const int nstages = blk.ncols / SN;
+  // the chunk's columns as a raw buffer (0x00020000: 32-bit raw data format)
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(P.y + (size_t)blk.col0 * DIM), 0, blk.ncols * DIM * 4, 0x00020000);
+  // byte offset of this lane inside piece i of a stage (piece = 2 rows): row parity, then the
+  // 16-byte chunk position XOR-swizzled by the row number
+  uint32_t yvoff[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) yvoff[i] = (uint32_t)((l >> 5) * (DIM * 4) + (((l & 31) ^ ((2 * i + (l >> 5)) & 15)) << 4));
+  constexpr auto PIECES = std::make_integer_sequence<int, 16>{};
 
   // first stage on its way before anything else
-  stage_load(ybase, smem, w, l);
+  stage_load(PIECES, ysrc, smem, w, yvoff, (uint32_t)(w * 16 * 1024));
 
   // A operands of the wave's two row tiles, scaled by -2 (exact): 2 x 16 x 16 bytes per lane
   float a0[64], a1[64];
@@ -417,7 +431,14 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   float nbn[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) nbn[ct] = ynp[32 * ct];
-  uint32_t* colpart_dst = P.colpart + (size_t)(blk.row0 / BM) * 3 * P.nb_pad + blk.col0 + 32 * w + r;
+  // this row block's column lists for the chunk's columns: three planes of nb_pad words
+  const uint32_t plane_bytes = (uint32_t)P.nb_pad * 4u;
+  const __amdgpu_buffer_rsrc_t coldst = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(P.colpart + (size_t)(blk.row0 / BM) * 3 * P.nb_pad + blk.col0), 0,
+      2 * plane_bytes + (uint32_t)blk.ncols * 4u, 0x00020000);
+  const uint32_t colvoff = (uint32_t)((32 * w + r) * 4);
+  const uint32_t colbuf_addr =
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + LDS_OFF_COLBUF + (uint32_t)((w * 3 * 32 + r) * 4);
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // stage 0 landed
@@ -431,14 +452,16 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     for (int ct = 0; ct < 4; ct++) bn[ct] = h == 0 ? 1.0f : nbn[ct];
     if (gg + 1 < nstages) {
 #ifndef SFM_ABLATE_GLDS
-      stage_load(ybase + (size_t)(gg + 1) * SN * DIM, smem + (u ^ 1) * LDS_STAGE_BYTES, w, l);
+      stage_load(PIECES, ysrc, smem + (u ^ 1) * LDS_STAGE_BYTES, w, yvoff,
+                 (uint32_t)((gg + 1) * LDS_STAGE_BYTES + w * 16 * 1024));
 #endif
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) nbn[ct] = ynp[(gg + 1) * SN + 32 * ct];
     }
     // column lists of the previous stage: each wave merges and stores 32 of its 128 columns
     if (gg >= 1 && h == 0)
-      stage_columns_out(colbuf + (u ^ 1) * LDS_COLBUF_WORDS, w, r, colpart_dst + (gg - 1) * SN, (size_t)P.nb_pad);
+      stage_columns_out(colbuf_addr + (u ^ 1) * LDS_COLBUF_WORDS * 4, coldst, colvoff, (uint32_t)((gg - 1) * SN * 4),
+                        plane_bytes);
     uint32_t tv = (uint32_t)(4 * gg);
     asm volatile("" : "+v"(tv));   // a VGPR, so that the row key is one v_and_or_b32
     uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 3) * 32 + r;
@@ -460,8 +483,8 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     stage_body(std::integral_constant<int, 1>{}, g + 1);
   }
   if (h == 0)
-    stage_columns_out(colbuf + ((nstages - 1) & 1) * LDS_COLBUF_WORDS, w, r, colpart_dst + (nstages - 1) * SN,
-                      (size_t)P.nb_pad);
+    stage_columns_out(colbuf_addr + ((nstages - 1) & 1) * LDS_COLBUF_WORDS * 4, coldst, colvoff,
+                      (uint32_t)((nstages - 1) * SN * 4), plane_bytes);
 
   // row lists: through LDS (the stage buffers are free now), one thread per row
   uint32_t* rowbuf = reinterpret_cast<uint32_t*>(smem);
@@ -505,10 +528,10 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     dst[1 * st] = t5.v1;
     dst[2 * st] = t5.v2;
     dst[3 * st] = t5.v3;
-    dst[4 * st] = c0 + ((t5.v0 & ~ROW_MASK) << 5) + t5.i0;
-    dst[5 * st] = c0 + ((t5.v1 & ~ROW_MASK) << 5) + t5.i1;
-    dst[6 * st] = c0 + ((t5.v2 & ~ROW_MASK) << 5) + t5.i2;
-    dst[7 * st] = c0 + ((t5.v3 & ~ROW_MASK) << 5) + t5.i3;
+    dst[4 * st] = c0 + ((t5.v0 & ROW_LOW) << 5) + t5.i0;
+    dst[5 * st] = c0 + ((t5.v1 & ROW_LOW) << 5) + t5.i1;
+    dst[6 * st] = c0 + ((t5.v2 & ROW_LOW) << 5) + t5.i2;
+    dst[7 * st] = c0 + ((t5.v3 & ROW_LOW) << 5) + t5.i3;
     dst[8 * st] = bound;
   }
 #ifdef SFM_K1_STAMPS
@@ -591,7 +614,8 @@ __device__ __forceinline__ void top2_merge(Top2& t, const Top2& o) {
 
 // Lower bound on the reference's squared sum of any column that is NOT among a
 // query's candidates, given the smallest key such a column can have.
-//   g  = computed |x|^2+|y|^2-2x.y; key value <= g (truncation and clamp only lower it);
+//   g  = computed |x|^2+|y|^2-2x.y; key value <= |g| (truncation only lowers it; a negative g has
+//        |g| below the error term that is subtracted, so its bound is <= 0 and still valid);
 //   |g - t| <= 3.1*gamma128*(nx+ny) + u*g  (norm sums, the 128-term fma chain started at
 //              -nx/2, the final fma), t = exact squared distance, u = 2^-24;
 //   reference sum r >= t*(1 - 131u).
@@ -687,7 +711,7 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
 #pragma unroll
             for (int e = 0; e < 3; e++) {
               const uint32_t key = k[u][e];
-              top5_put(t, key, (uint32_t)rb * BM + col_key_row(key & ~COL_MASK));
+              top5_put(t, key, (uint32_t)rb * BM + col_key_row(key & COL_LOW));
             }
             bound = bound < k[u][2] ? bound : k[u][2];   // a list's last key bounds what it left out
           }
