@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pairs-per-step", type=int, default=1,
                     help="pairs handed to one sfm_hip_match_pairs call (default 1: the headline configuration)")
+    ap.add_argument("--engine", choices=["f32", "f16x3"], default="f32",
+                    help="how the distance kernel forms its products (include/sfm_hip.h)")
     ap.add_argument("--untimed-pass", action="store_true",
                     help="after the timed region, run the same K steps once more without per-launch kernel "
                          "timing and report that rate as an extra field")
@@ -81,6 +83,7 @@ def main():
     from sfm_amd import synth
 
     m = sfm_amd.Matcher(local_rank if dist_on else 0)
+    m.set_engine(args.engine)
     A, B, truth = synth.make_pair(N_FEATURES, N_FEATURES, PLANTED, seed=2024 + rank)
     t0 = time.perf_counter()
     m.upload(0, A)

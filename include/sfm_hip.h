@@ -105,6 +105,20 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
                         int cross_check, int32_t* out_counts, int32_t* out_lhs_idx,
                         int32_t* out_rhs_idx, float* out_dist, int64_t out_stride);
 
+/* How the distance stage forms the 128-term products a.b of ||a||^2 + ||b||^2 - 2 a.b
+ * (the candidates it proposes are always re-ranked with the reference's exact fp32
+ * arithmetic, src/metric.hpp:15-22, and proven complete, so the matches are the same
+ * either way):
+ *   SFM_HIP_ENGINE_F32    fp32 matrix instructions on the descriptors as uploaded (default);
+ *   SFM_HIP_ENGINE_F16X3  each value split into two fp16 numbers (high + low part) and the
+ *                         product taken as hi.hi + hi.lo + lo.hi on the fp16 matrix
+ *                         instructions with fp32 accumulation: about the fp32 path's accuracy
+ *                         at several times its matrix throughput.
+ * Applies to calls of sfm_hip_match_pairs made after it.  No counterpart in the reference. */
+#define SFM_HIP_ENGINE_F32 0
+#define SFM_HIP_ENGINE_F16X3 1
+int sfm_hip_set_engine(sfm_hip_ctx* ctx, int engine);
+
 /* Wait for everything queued on the context (the reference's future.get(),
  * brute_force_matcher.cc:67-68,83). */
 int sfm_hip_sync(sfm_hip_ctx* ctx);

@@ -7,11 +7,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "lib", "libsfm_hip.so")
 
+ENGINES = {"f32": 0, "f16x3": 1}
+
 EXPORTS = (
     "sfm_hip_device_count", "sfm_hip_ctx_create", "sfm_hip_ctx_destroy", "sfm_hip_last_error",
     "sfm_hip_upload_image", "sfm_hip_drop_image", "sfm_hip_drop_all_images", "sfm_hip_image_size",
     "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
-    "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats",
+    "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats", "sfm_hip_set_engine",
 )
 
 
@@ -64,6 +66,7 @@ def library():
     lib.sfm_hip_host_free.argtypes = [vp]
     lib.sfm_hip_host_free.restype = None
     lib.sfm_hip_set_profiling.argtypes = [vp, ctypes.c_int]
+    lib.sfm_hip_set_engine.argtypes = [vp, ctypes.c_int]
     lib.sfm_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     lib.sfm_hip_reset_stats.argtypes = [vp]
     _lib = lib
@@ -179,6 +182,10 @@ class Matcher:
             c = int(cnt[k])
             out.append((lhs[k, :c].astype(np.int64), rhs[k, :c].astype(np.int64), dist[k, :c].copy()))
         return out
+
+    def set_engine(self, name):
+        """'f32' (fp32 matrix instructions) or 'f16x3' (split fp16 products): include/sfm_hip.h."""
+        self._check(self._lib.sfm_hip_set_engine(self._h, ENGINES[name]), "sfm_hip_set_engine")
 
     def set_profiling(self, on):
         self._check(self._lib.sfm_hip_set_profiling(self._h, int(bool(on))), "sfm_hip_set_profiling")

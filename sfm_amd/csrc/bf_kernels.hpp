@@ -79,6 +79,11 @@ struct PairDev {
   int32_t nchunks, chunk_cols;
   int32_t out_slot;      // index of this pair in the batch's output arrays
   int32_t pad_;
+  // split-half engine only: the images as scaled fp16 (high, low) planes and their scale factors
+  const uint16_t* xh;    // [na_pad][256]: see k_split for the layout of a row
+  const uint16_t* yh;
+  const float* xscale;   // {2^e, 2^-e}: the plane holds x * 2^e
+  const float* yscale;
 };
 
 // One workgroup of k_distance_topk.
@@ -93,6 +98,18 @@ struct BlockDev {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// How k_distance_topk forms the products x.y:
+//   ENGINE_F32   fp32 matrix instructions on the descriptors as they are;
+//   ENGINE_F16X3 every value v (scaled by a power of two per image) is split into two fp16 numbers
+//                hi = fp16(v), lo = fp16(v - hi), and x.y is taken as hi.hi + hi.lo + lo.hi on the
+//                fp16 matrix instructions with fp32 accumulation.  What is dropped is below
+//                2^-21 of |x||y|, the same order as the rounding of the fp32 chain, and is
+//                covered by the completeness bound of k_rerank like every other rounding.
+constexpr int ENGINE_F32 = 0;
+constexpr int ENGINE_F16X3 = 1;
 
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -108,8 +125,8 @@ __device__ __forceinline__ void insert3(uint32_t& a, uint32_t& b, uint32_t& c, u
   a = a < x ? a : x;
 }
 
-// Squared norms of the rows of one image, PAD_NORM for padding rows, and the
-// largest real norm in xn[n_pad].  One wave per row.
+// Squared norms of the rows of one image, PAD_NORM for padding rows, the largest real norm
+// in xn[n_pad] and the largest magnitude of any element in xn[n_pad + 1].  One wave per row.
 __global__ __launch_bounds__(256) void k_norms(const float* __restrict__ x, float* __restrict__ xn, int n,
                                                int n_pad) {
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -121,12 +138,55 @@ __global__ __launch_bounds__(256) void k_norms(const float* __restrict__ x, floa
   }
   float2 v = reinterpret_cast<const float2*>(x + (size_t)row * DIM)[l];
   float s = v.x * v.x + v.y * v.y;
+  float m = fmaxf(fabsf(v.x), fabsf(v.y));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    m = fmaxf(m, __shfl_xor(m, o));
+  }
   if (l == 0) {
     xn[row] = s;
     atomicMax(reinterpret_cast<unsigned int*>(xn + n_pad), __float_as_uint(s));
+    atomicMax(reinterpret_cast<unsigned int*>(xn + n_pad + 1), __float_as_uint(m));
   }
+}
+
+// Split-half planes of one image for ENGINE_F16X3.  With e chosen so that the largest magnitude
+// times 2^e lies in [512, 1024) (fp16 holds the high parts without overflow and the low parts of
+// all but negligible elements as normal numbers), every v = x * 2^e is split into hi = fp16(v)
+// and lo = fp16(v - hi), both round-to-nearest.  A row of the plane is 256 halves = 512 bytes in
+// 16-byte pieces: for k-slab s (16 consecutive k) pieces 4s, 4s+1 hold hi[16s .. 16s+7],
+// hi[16s+8 .. 16s+15] and pieces 4s+2, 4s+3 the same of lo -- the order in which the matrix
+// instruction's lanes (row, half) consume them.  One thread per 8 elements.
+__global__ __launch_bounds__(256) void k_split(const float* __restrict__ x, const float* __restrict__ xn,
+                                               uint16_t* __restrict__ plane, float* __restrict__ scale, int n_pad) {
+  const float amax = xn[n_pad + 1];
+  int k = 0;
+  (void)frexpf(amax, &k);                   // amax = m * 2^k, m in [0.5, 1)
+  int e = amax > 0.0f ? 10 - k : 0;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  const float sc = ldexpf(1.0f, e);
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) {
+    scale[0] = sc;
+    scale[1] = ldexpf(1.0f, -e);
+  }
+  const size_t row = t >> 4;
+  const int g = (int)(t & 15);              // elements 8g .. 8g+7: slab g>>1, half g&1
+  if (row >= (size_t)n_pad) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(x + row * DIM + 8 * g);
+  const f32x4 a = src[0], b = src[1];
+  const float v[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, b.x * sc, b.y * sc, b.z * sc, b.w * sc};
+  f16x8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const _Float16 h = (_Float16)v[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(v[i] - (float)h);
+  }
+  f16x8* dst = reinterpret_cast<f16x8*>(plane + row * 256);
+  dst[4 * (g >> 1) + (g & 1)] = hi;
+  dst[4 * (g >> 1) + 2 + (g & 1)] = lo;
 }
 
 // ---------------------------------------------------------------------------
@@ -238,12 +298,16 @@ __device__ __forceinline__ void anchor16(uint32_t (&x)[16]) {
                "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
 }
 
-// Step S of a tile pair: fetch B fragment S+2, retire fragment S, 4 MFMAs for each of the
-// wave's two row tiles.  TOFF = byte offset of the column tile inside its stage buffer;
-// ROT: fragment s lives in b[(s + ROT) % 3]; HAS_NEXT: the next column tile is in the same
-// stage (16 KiB further) and its first two fragments are fetched by the last two steps.
-template <int TOFF, int S, int ROT, bool HAS_NEXT>
-__device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const float (&a0)[64], const float (&a1)[64],
+// Step S of a tile pair: fetch B fragment S+2, retire fragment S, then the matrix instructions
+// that consume it for each of the wave's two row tiles.  TOFF = byte offset of the column tile
+// inside its stage buffer; ROT: fragment s lives in b[(s + ROT) % 3]; HAS_NEXT: the next column
+// tile is in the same stage (16 KiB further) and its first two fragments are fetched by the last
+// two steps.  Fragment S is the 16 bytes at piece 2S + h of the lane's row.
+//   ENGINE_F32:   four k-steps of v_mfma_f32_32x32x2_f32 per row tile;
+//   ENGINE_F16X3: even S = high halves of k-slab S/2: products with the high and the low halves of A;
+//                 odd S = low halves of the slab: product with the high halves of A.
+template <int ENGINE, int TOFF, int S, int ROT, bool HAS_NEXT>
+__device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const f32x4 (&a0)[16], const f32x4 (&a1)[16],
                                           f32x4 (&b)[3], const uint32_t (&X)[8]) {
   if constexpr (S + 2 < 16) {
     lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(S + 2 + ROT) % 3], X[(S + 2) & 7]);
@@ -255,22 +319,35 @@ __device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const floa
     lds_wait<15 - S>();
   }
   const f32x4 bs = b[(S + ROT) % 3];
-  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[4 * S + 0], bs.x, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * S + 0], bs.x, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[4 * S + 1], bs.y, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * S + 1], bs.y, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[4 * S + 2], bs.z, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * S + 2], bs.z, acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[4 * S + 3], bs.w, acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * S + 3], bs.w, acc1, 0, 0, 0);
+  if constexpr (ENGINE == ENGINE_F32) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S].x, bs.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S].x, bs.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S].y, bs.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S].y, bs.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S].z, bs.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S].z, bs.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S].w, bs.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S].w, bs.w, acc1, 0, 0, 0);
+  } else {
+    const f16x8 bh = __builtin_bit_cast(f16x8, bs);
+    if constexpr ((S & 1) == 0) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S]), bh, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S]), bh, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S + 1]), bh, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S + 1]), bh, acc1, 0, 0, 0);
+    } else {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S - 1]), bh, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S - 1]), bh, acc1, 0, 0, 0);
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int TOFF, int ROT, bool HAS_NEXT, int... S>
+template <int ENGINE, int TOFF, int ROT, bool HAS_NEXT, int... S>
 __device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32x16& acc0, f32x16& acc1,
-                                           const float (&a0)[64], const float (&a1)[64], f32x4 (&b)[3],
+                                           const f32x4 (&a0)[16], const f32x4 (&a1)[16], f32x4 (&b)[3],
                                            const uint32_t (&X)[8]) {
-  (pair_step<TOFF, S, ROT, HAS_NEXT>(acc0, acc1, a0, a1, b, X), ...);
+  (pair_step<ENGINE, TOFF, S, ROT, HAS_NEXT>(acc0, acc1, a0, a1, b, X), ...);
 }
 
 // Fold one finished accumulator tile into the lane's row lists and column list.
@@ -289,8 +366,8 @@ __device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLi
 // One column tile (32 columns) against the wave's 64 rows: 2 x 65 MFMAs, then the vector
 // epilogue for both accumulator tiles, then the column lists (over the wave's 64 rows) are
 // merged across the two half-waves and parked in LDS.
-template <int CT>
-__device__ __forceinline__ void tile_pair(const float (&a0)[64], const float (&a1)[64], float an0, float an1, float bn,
+template <int ENGINE, int CT>
+__device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
                                           f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tv, LaneLists& L0,
                                           LaneLists& L1, uint32_t lowc, int h, uint32_t* cb) {
   constexpr int TOFF = CT * 32 * DIM * 4;
@@ -303,7 +380,7 @@ __device__ __forceinline__ void tile_pair(const float (&a0)[64], const float (&a
   for (int i = 0; i < 16; i++) zero[i] = 0.0f;
   f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
   f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
-  pair_steps<TOFF, CT % 3, (CT < 3)>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X);
+  pair_steps<ENGINE, TOFF, CT % 3, (CT < 3)>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X);
 
   uint32_t cl0 = SENT, cl1 = SENT, cl2 = SENT;
 #ifdef SFM_ABLATE_FOLD
@@ -355,6 +432,7 @@ __device__ __forceinline__ void stage_columns_out(uint32_t cbaddr, __amdgpu_buff
 __device__ unsigned long long* g_stamps;
 #endif
 
+template <int ENGINE>
 __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restrict__ pairs,
                                                           const BlockDev* __restrict__ blocks) {
   __shared__ __attribute__((aligned(1024))) char smem[LDS_TOTAL];
@@ -377,8 +455,10 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 
   const int nstages = blk.ncols / SN;
   // the chunk's columns as a raw buffer (0x00020000: 32-bit raw data format)
+  // (both engines stream 512-byte rows: 128 floats, or 128 + 128 halves)
+  const char* yrows = ENGINE == ENGINE_F32 ? reinterpret_cast<const char*>(P.y) : reinterpret_cast<const char*>(P.yh);
   const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(P.y + (size_t)blk.col0 * DIM), 0, blk.ncols * DIM * 4, 0x00020000);
+      (void*)(yrows + (size_t)blk.col0 * DIM * 4), 0, blk.ncols * DIM * 4, 0x00020000);
   // byte offset of this lane inside piece i of a stage (piece = 2 rows): row parity, then the
   // 16-byte chunk position XOR-swizzled by the row number
   uint32_t yvoff[8];
@@ -389,26 +469,49 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   // first stage on its way before anything else
   stage_load(PIECES, ysrc, smem, w, yvoff, (uint32_t)(w * 16 * 1024));
 
-  // A operands of the wave's two row tiles, scaled by -2 (exact): 2 x 16 x 16 bytes per lane
-  float a0[64], a1[64];
-  {
+  // A operands of the wave's two row tiles, scaled by -2 (exact): 2 x 16 x 16 bytes per lane,
+  // piece 2s + h of the lane's row for s < 16 (fp32 values, or fp16 pairs of the split planes)
+  f32x4 a0[16], a1[16];
+  float sigma = 1.0f;   // ENGINE_F16X3: the accumulators hold distances times 2^(ex + ey)
+  if constexpr (ENGINE == ENGINE_F32) {
     const f32x4* xr0 = reinterpret_cast<const f32x4*>(P.x + (size_t)(blk.row0 + 64 * w + r) * DIM);
     const f32x4* xr1 = xr0 + 32 * (DIM / 4);
 #pragma unroll
     for (int s = 0; s < 16; s++) {
-      const f32x4 u = xr0[2 * s + h], v = xr1[2 * s + h];
-      a0[4 * s + 0] = -2.0f * u.x; a0[4 * s + 1] = -2.0f * u.y; a0[4 * s + 2] = -2.0f * u.z; a0[4 * s + 3] = -2.0f * u.w;
-      a1[4 * s + 0] = -2.0f * v.x; a1[4 * s + 1] = -2.0f * v.y; a1[4 * s + 2] = -2.0f * v.z; a1[4 * s + 3] = -2.0f * v.w;
+      a0[s] = -2.0f * xr0[2 * s + h];
+      a1[s] = -2.0f * xr1[2 * s + h];
+    }
+  } else {
+    const f32x4* xr0 = reinterpret_cast<const f32x4*>(P.xh + (size_t)(blk.row0 + 64 * w + r) * 256);
+    const f32x4* xr1 = xr0 + 32 * (DIM / 4);
+    const f16x8 m2 = {-2, -2, -2, -2, -2, -2, -2, -2};
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      a0[s] = __builtin_bit_cast(f32x4, __builtin_bit_cast(f16x8, xr0[2 * s + h]) * m2);
+      a1[s] = __builtin_bit_cast(f32x4, __builtin_bit_cast(f16x8, xr1[2 * s + h]) * m2);
+    }
+    sigma = P.xscale[0] * P.yscale[0];
+  }
+  // Park the A operands in the accumulator half of the register file: only matrix instructions
+  // read them (their sources may be AGPRs), which leaves the vector half to the lists and
+  // accumulators that the epilogue's vector instructions work on.
+  // (the fp32 instructions take single registers, the fp16 ones aligned groups of four)
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if constexpr (ENGINE == ENGINE_F32) {
+      asm volatile("" : "+a"(a0[i].x), "+a"(a1[i].x));
+      asm volatile("" : "+a"(a0[i].y), "+a"(a1[i].y));
+      asm volatile("" : "+a"(a0[i].z), "+a"(a1[i].z));
+      asm volatile("" : "+a"(a0[i].w), "+a"(a1[i].w));
+    } else {
+      asm volatile("" : "+a"(a0[i]), "+a"(a1[i]));
     }
   }
-  // Park the A operands in the accumulator half of the register file: only MFMAs read them
-  // (an MFMA source may be an AGPR), which leaves the vector half to the lists and accumulators
-  // that the epilogue's vector instructions work on.
-#pragma unroll
-  for (int i = 0; i < 64; i++) asm volatile("" : "+a"(a0[i]), "+a"(a1[i]));
-  // operands of the norm MFMA: A = [|x_r|^2, 1], B = [1, |y_c|^2] over k = (h = 0, h = 1)
-  const float an0 = h == 0 ? P.xn[blk.row0 + 64 * w + r] : 1.0f;
-  const float an1 = h == 0 ? P.xn[blk.row0 + 64 * w + 32 + r] : 1.0f;
+  // operands of the norm MFMA: A = [|x_r|^2, 1], B = [1, |y_c|^2] over k = (h = 0, h = 1);
+  // padding rows and columns get an infinite norm whatever the scale
+  auto scaled_norm = [sigma](float n) { return n >= PAD_NORM ? __builtin_inff() : n * sigma; };
+  const float an0 = h == 0 ? scaled_norm(P.xn[blk.row0 + 64 * w + r]) : 1.0f;
+  const float an1 = h == 0 ? scaled_norm(P.xn[blk.row0 + 64 * w + 32 + r]) : 1.0f;
 
   LaneLists L0, L1;
 #pragma unroll
@@ -449,7 +552,7 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     constexpr int u = decltype(UC)::value;
     float bn[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) bn[ct] = h == 0 ? 1.0f : nbn[ct];
+    for (int ct = 0; ct < 4; ct++) bn[ct] = h == 0 ? 1.0f : scaled_norm(nbn[ct]);
     if (gg + 1 < nstages) {
 #ifndef SFM_ABLATE_GLDS
       stage_load(PIECES, ysrc, smem + (u ^ 1) * LDS_STAGE_BYTES, w, yvoff,
@@ -467,10 +570,10 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 3) * 32 + r;
     f32x4 b[3];
     const uint32_t (&X)[8] = u == 0 ? X0 : X1;
-    tile_pair<0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 96);
-    tile_pair<1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 96);
-    tile_pair<2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 96);
-    tile_pair<3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 96);
+    tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 96);
+    tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 96);
+    tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 96);
+    tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 96);
     // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
     // compiler does not always drain it for __syncthreads(), so wait explicitly.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -626,6 +729,27 @@ __device__ __forceinline__ double excluded_lower_bound(uint32_t boundkey, uint32
   return bv * (1.0 - 160.0 * u) - 450.0 * u * ((double)nq + (double)nomax);
 }
 
+// The same for ENGINE_F16X3, whose keys are distances times sigma = sq * so (the two images'
+// power-of-two scales).  In scaled units, with nx', ny' the scaled squared norms:
+//   * norm sums: 128u each; the accumulation: one fp32 step for the norms and 24 fp16 steps
+//     of 16 products (exact in fp32) each, at most 17 roundings per step on partial sums
+//     below 2(nx'+ny')(1+2^-10): 3 + 24*17 = 411 roundings, 822u(nx'+ny');
+//   * split residue of an element v: |v - hi - lo| <= 2^-22 |v|, or <= 2^-14 absolute should the
+//     matrix unit flush an fp16 subnormal low part; the dropped lo.lo products are below
+//     2^-22 |x_k||y_k|.  Together, times the factor 2 of -2x.y:
+//       3 * 2^-22 * 2|x'||y'|  <=  12u (nx'+ny'),   2 * 2^-14 * sqrt(128) * (|x'| + |y'|).
+// 1100u covers the relative part with margin; the absolute part is kept as it is.
+__device__ __forceinline__ double excluded_lower_bound_split(uint32_t boundkey, uint32_t mask, float nq, float nomax,
+                                                             float sq, float so) {
+  const double u = 5.9604644775390625e-8;
+  const double sigma = (double)sq * (double)so;
+  const double bv = (double)__uint_as_float(boundkey & mask);
+  const double floor_term = 2.0 * 6.103515625e-5 * 11.32 *
+                            (sqrt((double)nq) * (double)sq + sqrt((double)nomax) * (double)so);
+  const double scaled = bv * (1.0 - 160.0 * u) - 1100.0 * u * sigma * ((double)nq + (double)nomax) - floor_term;
+  return scaled / sigma;
+}
+
 constexpr int RR_QUERIES = 64;       // queries per workgroup of k_rerank
 constexpr int RR_SQ_STRIDE = 132;    // words per row of squares (128 + 4: conflict-free b128 reads)
 
@@ -641,7 +765,7 @@ constexpr int RR_SQ_STRIDE = 132;    // words per row of squares (128 + 4: confl
 //      and checks the completeness bound;
 //   D. queries that failed the check are re-answered by an exact scan of every
 //      candidate row, by the whole workgroup.
-__global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pairs, double ratio,
+__global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pairs, double ratio, int engine,
                                                 unsigned long long* __restrict__ rescanned) {
   __shared__ __attribute__((aligned(16))) float sq[128 * RR_SQ_STRIDE];
   __shared__ uint32_t cand[RR_QUERIES * NCAND];
@@ -812,7 +936,13 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
     bool safe = no <= NCAND || bound == SENT;
     if (!safe) {
       const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
-      safe = (double)t.r2 <= excluded_lower_bound(bound, mask, qn[q], on[opad]);
+      if (engine == ENGINE_F32) {
+        safe = (double)t.r2 <= excluded_lower_bound(bound, mask, qn[q], on[opad]);
+      } else {
+        const float sq = dir == 0 ? P.xscale[0] : P.yscale[0];
+        const float so = dir == 0 ? P.yscale[0] : P.xscale[0];
+        safe = (double)t.r2 <= excluded_lower_bound_split(bound, mask, qn[q], on[opad], sq, so);
+      }
     }
     const bool accept = (double)t.d1 < ratio * (double)t.d2;   // brute_force_matcher.cc:35
     int32_t* best = dir == 0 ? P.fwd_best : P.rev_best;

@@ -20,8 +20,10 @@ namespace {
 thread_local std::string g_last_error;  // failures without a context
 
 struct Image {
-  float* d = nullptr;    // [n_pad][128]
-  float* norms = nullptr;  // [n_pad + 1]
+  float* d = nullptr;       // [n_pad][128]
+  float* norms = nullptr;   // [n_pad + 2]: squared norms, then the largest norm and the largest magnitude
+  uint16_t* split = nullptr;  // [n_pad][256] scaled fp16 (high, low) planes: see k_split
+  float* scale = nullptr;   // {2^e, 2^-e} of the split planes
   int32_t n = 0, n_pad = 0;
 };
 
@@ -64,6 +66,7 @@ struct sfm_hip_ctx {
   std::string last_error;
   unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
 
+  int engine = SFM_HIP_ENGINE_F32;
   bool profiling = false;
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
@@ -125,6 +128,8 @@ int ensure_stage(sfm_hip_ctx* ctx, Lane& L, int slot, size_t bytes) {
 void free_image(Image& im) {
   if (im.d) (void)hipFree(im.d);
   if (im.norms) (void)hipFree(im.norms);
+  if (im.split) (void)hipFree(im.split);
+  if (im.scale) (void)hipFree(im.scale);
   im = Image();
 }
 
@@ -291,18 +296,25 @@ int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descri
   im.n_pad = (int32_t)align_up((size_t)std::max(n, 1), IMG_PAD);
   const size_t row_bytes = DIM * sizeof(float);
   HIP_TRY(ctx, hipMalloc((void**)&im.d, (size_t)im.n_pad * row_bytes));
-  hipError_t e = hipMalloc((void**)&im.norms, ((size_t)im.n_pad + 1) * sizeof(float));
+  hipError_t e = hipMalloc((void**)&im.norms, ((size_t)im.n_pad + 2) * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&im.split, (size_t)im.n_pad * 256 * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&im.scale, 2 * sizeof(float));
   if (e != hipSuccess) {
     free_image(im);
-    return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc norms: ") + hipGetErrorString(e));
+    return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc image planes: ") + hipGetErrorString(e));
   }
   e = hipSuccess;
   if (n > 0) e = hipMemcpyAsync(im.d, descriptors, (size_t)n * row_bytes, hipMemcpyHostToDevice, up);
   if (e == hipSuccess && im.n_pad > n)
     e = hipMemsetAsync(im.d + (size_t)n * DIM, 0, (size_t)(im.n_pad - n) * row_bytes, up);
-  if (e == hipSuccess) e = hipMemsetAsync(im.norms + im.n_pad, 0, sizeof(float), up);
+  if (e == hipSuccess) e = hipMemsetAsync(im.norms + im.n_pad, 0, 2 * sizeof(float), up);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_norms, dim3((im.n_pad + 3) / 4), dim3(256), 0, up, im.d, im.norms, n, im.n_pad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_split, dim3((unsigned)(((size_t)im.n_pad * 16 + 255) / 256)), dim3(256), 0, up, im.d, im.norms,
+                       im.split, im.scale, im.n_pad);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(up);
@@ -478,6 +490,10 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       d.chunk_cols = pl.chunk_cols;
       d.out_slot = k;
       d.pad_ = 0;
+      d.xh = pl.X->split;
+      d.yh = pl.Y->split;
+      d.xscale = pl.X->scale;
+      d.yscale = pl.Y->scale;
       if (pl.X->n > 0 && pl.Y->n > 0) {
         // chunk-major: workgroups that run together stream the same columns
         for (int c = 0; c < pl.nchunks; c++) {
@@ -525,7 +541,10 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
         tl.flop = flop;
         HIP_TRY(ctx, hipEventRecord(tl.start, st));
       }
-      hipLaunchKernelGGL(k_distance_topk, dim3((unsigned)n_blocks), dim3(256), 0, st, dp, db);
+      if (ctx->engine == SFM_HIP_ENGINE_F16X3)
+        hipLaunchKernelGGL(k_distance_topk<ENGINE_F16X3>, dim3((unsigned)n_blocks), dim3(256), 0, st, dp, db);
+      else
+        hipLaunchKernelGGL(k_distance_topk<ENGINE_F32>, dim3((unsigned)n_blocks), dim3(256), 0, st, dp, db);
       HIP_TRY(ctx, hipGetLastError());
       if (ctx->profiling) {
         HIP_TRY(ctx, hipEventRecord(tl.stop, st));
@@ -546,7 +565,8 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     const int max_q = cross_check ? std::max(max_na, max_nb) : max_na;
     if (max_q > 0) {
       hipLaunchKernelGGL(k_rerank, dim3((max_q + RR_QUERIES - 1) / RR_QUERIES, count, cross_check ? 2 : 1), dim3(256), 0,
-                         st, dp, ratio, ctx->rescanned_dev);
+                         st, dp, ratio, ctx->engine == SFM_HIP_ENGINE_F16X3 ? ENGINE_F16X3 : ENGINE_F32,
+                         ctx->rescanned_dev);
       HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_cross_compact, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
@@ -583,6 +603,14 @@ void* sfm_hip_host_alloc(size_t bytes) {
 
 void sfm_hip_host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+
+int sfm_hip_set_engine(sfm_hip_ctx* ctx, int engine) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (engine != SFM_HIP_ENGINE_F32 && engine != SFM_HIP_ENGINE_F16X3)
+    return fail(ctx, SFM_HIP_ERR_INVALID, "unknown engine " + std::to_string(engine));
+  ctx->engine = engine;
+  return SFM_HIP_OK;
 }
 
 int sfm_hip_set_profiling(sfm_hip_ctx* ctx, int enabled) {

@@ -26,10 +26,12 @@ def kat_descriptors(rows):
     return a
 
 
-@pytest.fixture(scope="session")
-def matcher():
-    """One GPU context for the whole session (GPU tests only)."""
+@pytest.fixture(scope="session", params=["f32", "f16x3"])
+def matcher(request):
+    """One GPU context per distance engine for the whole session (GPU tests only): every parity
+    test runs once with the fp32 matrix path and once with the split-fp16 path."""
     import sfm_amd
     m = sfm_amd.Matcher(0)
+    m.set_engine(request.param)
     yield m
     m.close()
