@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 
 N_FEATURES = 8192
 PLANTED = 4096
-PEAK_FP32_MFMA_TFLOPS = 157.3  # 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_FP32_MFMA_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_FP16_MFMA_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (dense)
 
 
 def cpu_baseline(A, B, expected):
@@ -46,6 +47,28 @@ def cpu_baseline(A, B, expected):
             "all_cores": {"value": 1.0 / t16, "cores": 16, "seconds_per_pair": t16}}
 
 
+def roofline(st, engine, traffic):
+    """Distance kernel against the matrix-instruction peak of the type it multiplies in.
+
+    achieved counts the algorithmic work only: 2*Na*Nb*128 FLOP per pair, once, however many
+    partial products the engine actually issues (the split-fp16 engine issues three per term).
+    """
+    if not st["distance_launches"]:
+        return None
+    avg_ms = st["distance_ms"] / st["distance_launches"]
+    per_launch = st["distance_flop"] / st["distance_launches"]
+    achieved = per_launch / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_FP32_MFMA_TFLOPS if engine == "f32" else PEAK_FP16_MFMA_TFLOPS
+    r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+         "traffic": traffic, "kernel": "k_distance_topk<%s>" % engine, "avg_launch_ms": avg_ms,
+         "flop_per_launch": per_launch}
+    if engine == "f16x3":
+        # what the matrix units execute: 24 fp16 instructions of 32x32x16 and one fp32 32x32x2 per tile
+        r["executed_over_algorithmic"] = (24 * 16 + 2) / 128.0
+        r["executed_frac_of_peak"] = r["frac"] * r["executed_over_algorithmic"]
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +79,8 @@ def main():
                     help="pairs handed to one sfm_hip_match_pairs call (default 1: the headline configuration)")
     ap.add_argument("--engine", choices=["f32", "f16x3"], default="f32",
                     help="how the distance kernel forms its products (include/sfm_hip.h)")
+    ap.add_argument("--no-other-engine", action="store_true",
+                    help="do not time the library's other distance engine after the main run")
     ap.add_argument("--untimed-pass", action="store_true",
                     help="after the timed region, run the same K steps once more without per-launch kernel "
                          "timing and report that rate as an extra field")
@@ -96,22 +121,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    m.set_profiling(not args.no_profile_events)
-    for _ in range(args.warmup):
-        m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
-    m.sync()
-    m.reset_stats()
+    def timed_region(engine):
+        """W untimed steps, then K timed steps between barriers; per-launch kernel timing on."""
+        m.set_engine(engine)
+        m.set_profiling(not args.no_profile_events)
+        for _ in range(args.warmup):
+            m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+        m.sync()
+        m.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+        m.sync()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        st = m.stats()
+        m.set_profiling(False)
+        return out, elapsed, st
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
-    m.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    st = m.stats()
-    m.set_profiling(False)
+    out, elapsed, st = timed_region(args.engine)
     # extra information outside the timed region: the same K steps without per-launch kernel timing
     # (the library then lets consecutive distance kernels overlap at their edges)
     free_rate = None
@@ -135,20 +164,14 @@ def main():
         total_pairs = args.steps * world * args.pairs_per_step
         value = total_pairs / elapsed
         flop_per_launch = 2.0 * N_FEATURES * N_FEATURES * 128
-        roof = None
         # HBM-side bytes per launch of the distance kernel come from a separate hardware-counter
         # run of this same workload (tools/collect_profiles.sh), kept beside the profiles.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "distance_kernel_traffic.json")
         if os.path.exists(tpath) and args.pairs_per_step == 1:
             with open(tpath) as fh:
-                traffic = json.load(fh).get("traffic_bytes_per_launch")
-        if st["distance_launches"]:
-            avg_ms = st["distance_ms"] / st["distance_launches"]
-            achieved = st["distance_flop"] / st["distance_launches"] / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                    "kernel": "k_distance_topk", "avg_launch_ms": avg_ms, "flop_per_launch": flop_per_launch * args.pairs_per_step}
+                traffic = json.load(fh).get(args.engine, {}).get("traffic_bytes_per_launch")
+        roof = roofline(st, args.engine, traffic)
         planted_found = len(set(zip(got[0].tolist(), got[1].tolist())) & set(map(tuple, truth.tolist())))
         line = {
             "metric": "image pairs/sec, 8k x 8k 128-d descriptors",
@@ -157,7 +180,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "single synthetic pair, 8192x8192 128-d float descriptors, "
                                    "ratio 0.8 + cross-check (BASELINE.json configs[1])",
-                       "pairs_per_step_per_gpu": args.pairs_per_step, "planted_matches": PLANTED, "matches_found": cnt,
+                       "engine": args.engine, "pairs_per_step_per_gpu": args.pairs_per_step, "planted_matches": PLANTED, "matches_found": cnt,
                        "planted_found": planted_found, "parallelism": "pairs sharded over ranks, no collective"},
             "frac_of_fp32_mfma_peak_end_to_end": value / world * flop_per_launch / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "rescanned_queries_per_pair": st["rescanned_queries"] / max(1, st["pairs"]),
@@ -165,6 +188,19 @@ def main():
             "pairs_per_s_this_gpu_without_kernel_timing": free_rate,
             "roofline": roof,
         }
+        if world == 1 and not args.no_other_engine:
+            # the library's other distance engine on the same steps (its own timed region)
+            other = "f16x3" if args.engine == "f32" else "f32"
+            o_out, o_elapsed, o_st = timed_region(other)
+            o_cnt = int(o_out[0][0])
+            same = (o_cnt == cnt and o_out[1][0, :cnt].tolist() == got[0].tolist()
+                    and o_out[2][0, :cnt].tolist() == got[1].tolist())
+            o_value = args.steps * args.pairs_per_step / o_elapsed
+            line["other_engine"] = {
+                "engine": other, "value": o_value, "unit": "pairs/s", "ms_per_step": o_elapsed / args.steps * 1e3,
+                "frac_of_fp32_mfma_peak_end_to_end": o_value * flop_per_launch / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                "rescanned_queries_per_pair": o_st["rescanned_queries"] / max(1, o_st["pairs"]),
+                "matches_equal_main_engine": bool(same), "roofline": roofline(o_st, other, None)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, B, got)
         print(json.dumps(line), flush=True)

@@ -61,7 +61,7 @@ void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int
 // Two sets of pinned result buffers alternate, so the GPU works on batch b while this thread
 // turns batch b-1 into Match records.
 void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t hi, double ratio, bool cross,
-                Progress& progress) {
+                int engine, Progress& progress) {
   sfm_hip_ctx* ctx = nullptr;
   if (sfm_hip_ctx_create(device, &ctx) != SFM_HIP_OK) fail(nullptr, "sfm_hip_ctx_create");
   struct Guard {
@@ -73,6 +73,7 @@ void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t 
       sfm_hip_ctx_destroy(c);
     }
   } guard{ctx, {}};
+  if (engine >= 0 && sfm_hip_set_engine(ctx, engine) != SFM_HIP_OK) fail(ctx, "sfm_hip_set_engine");
 
   std::map<IndexT, const Descriptors*> images;
   int64_t stride = 1;
@@ -158,6 +159,15 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
     want = env ? std::atoi(env) : visible;
     if (want <= 0) want = visible;
   }
+  int engine = engine_;
+  if (engine < 0) {
+    if (const char* env = std::getenv("SFM_HIP_ENGINE")) {
+      const std::string name(env);
+      if (name == "f32") engine = SFM_HIP_ENGINE_F32;
+      else if (name == "f16x3") engine = SFM_HIP_ENGINE_F16X3;
+      else throw std::runtime_error("HipBruteForceMatcher: SFM_HIP_ENGINE must be f32 or f16x3, got '" + name + "'");
+    }
+  }
   // std::set order: lexicographic.  The maps are not modified from here on, so the pointers
   // taken now stay valid while the workers run, and each worker writes only its own pairs' lists.
   std::vector<PairJob> jobs;
@@ -180,7 +190,7 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
     const size_t hi = lo + base + ((size_t)d < extra ? 1 : 0);
     workers.emplace_back([&, d, lo, hi] {
       try {
-        run_device(d, jobs, lo, hi, ratio_, is_cross_valid, progress);
+        run_device(d, jobs, lo, hi, ratio_, is_cross_valid, engine, progress);
       } catch (...) {
         errors[(size_t)d] = std::current_exception();
       }

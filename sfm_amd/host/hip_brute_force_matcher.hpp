@@ -10,6 +10,8 @@
 //     reads out of bounds (brute_force_matcher.cc:36);
 //   * the work is spread over every visible GPU (or SFM_HIP_DEVICES=n of them) instead of the
 //     reference's two worker threads.
+// The distance engine (include/sfm_hip.h: SFM_HIP_ENGINE_F32 / SFM_HIP_ENGINE_F16X3) can be chosen
+// with set_engine() or the environment variable SFM_HIP_ENGINE=f32|f16x3; the matches are the same.
 #ifndef SFM_AMD_HOST_HIP_BRUTE_FORCE_MATCHER_HPP_
 #define SFM_AMD_HOST_HIP_BRUTE_FORCE_MATCHER_HPP_
 #include "feature_matcher_interface.hpp"
@@ -21,11 +23,14 @@ class HipBruteForceMatcher : public FeatureMatcherInterface {
       : n_devices_(n_devices), ratio_(ratio), print_progress_(print_progress) {}
   void Match(SfMData& sfm_data, const std::set<Pair>& pairs, bool is_cross_valid = true) override;
   ~HipBruteForceMatcher() override = default;
+  // engine < 0: use SFM_HIP_ENGINE if set, else the library's default.
+  void set_engine(int engine) { engine_ = engine; }
 
  private:
   int n_devices_;
   double ratio_;        // the reference hard-codes 0.8 (brute_force_matcher.cc:35)
   bool print_progress_;
+  int engine_ = -1;
 };
 
 // When this file is compiled into the reference tree in place of brute_force_matcher.cc,

@@ -3,7 +3,8 @@
 // (uploads, GPU matching on every visible device, Match records built on the host) and report
 // pairs per second over the whole call.
 //
-//   match_set_bench <n_images> <n_features> [planted_fraction=0.5] [devices=0]
+//   match_set_bench <n_images> <n_features> [planted_fraction=0.5] [devices=0] [engine=-1]
+//   (engine: -1 library default / SFM_HIP_ENGINE, 0 fp32 matrix instructions, 1 split fp16)
 //
 // Images share a pool of "scene" descriptors (non-negative rows of unit length, as RootSIFT
 // produces: vlfeat_feature_extractor.cc:15-22); each image takes planted_fraction of its rows from
@@ -47,13 +48,14 @@ void scene_row(Rng& rng, float* row) {
 
 int main(int argc, char** argv) {
   if (argc < 3) {
-    std::fprintf(stderr, "usage: %s <n_images> <n_features> [planted_fraction] [devices]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <n_images> <n_features> [planted_fraction] [devices] [engine]\n", argv[0]);
     return 2;
   }
   const int n_images = std::atoi(argv[1]);
   const int n_feat = std::atoi(argv[2]);
   const double planted = argc > 3 ? std::atof(argv[3]) : 0.5;
   const int devices = argc > 4 ? std::atoi(argv[4]) : 0;
+  const int engine = argc > 5 ? std::atoi(argv[5]) : -1;
   const int n_planted = (int)(planted * n_feat);
 
   Rng rng{12345};
@@ -86,6 +88,7 @@ int main(int argc, char** argv) {
   std::set<Pair> pairs;
   ExhaustivePairBuilder().BuildPair(data, pairs);
   HipBruteForceMatcher matcher(devices, 0.8, /*print_progress=*/false);
+  matcher.set_engine(engine);
   const auto t0 = std::chrono::steady_clock::now();
   matcher.Match(data, pairs, true);
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -96,8 +99,8 @@ int main(int argc, char** argv) {
     for (const Match& m : list)   // keypoints encode (feature index, image id)
       if (m.lhs_observation.x() != (double)m.lhs_idx || m.rhs_observation.y() != (double)pair.second) wrong++;
   }
-  std::printf("{\"images\": %d, \"features\": %d, \"pairs\": %zu, \"seconds\": %.4f, \"pairs_per_s\": %.1f, "
+  std::printf("{\"engine\": %d, \"images\": %d, \"features\": %d, \"pairs\": %zu, \"seconds\": %.4f, \"pairs_per_s\": %.1f, "
               "\"matches\": %zu, \"matches_per_pair\": %.1f, \"observation_mismatches\": %zu}\n",
-              n_images, n_feat, pairs.size(), sec, pairs.size() / sec, total, (double)total / pairs.size(), wrong);
+              engine, n_images, n_feat, pairs.size(), sec, pairs.size() / sec, total, (double)total / pairs.size(), wrong);
   return wrong ? 1 : 0;
 }

@@ -45,4 +45,5 @@ def test_null_arguments_are_rejected_not_dereferenced():
     assert lib.sfm_hip_upload_image(None, 0, None, 0) != 0
     assert lib.sfm_hip_match_pairs(None, None, 0, 0.8, 1, None, None, None, None, 0) != 0
     assert lib.sfm_hip_device_count(None) != 0
+    assert lib.sfm_hip_set_engine(None, 0) != 0
     assert b"null" in lib.sfm_hip_last_error(None)

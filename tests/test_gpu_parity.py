@@ -21,6 +21,13 @@ def run_pair(m, A, B, ratio=0.8, cross=True, ids=(0, 1)):
     return l, r, d
 
 
+def check_pair(m, A, B, cross, ratio=0.8):
+    got = run_pair(m, A, B, ratio, cross)
+    exp = oracle.match_pair(A, B, ratio, cross, threads=8)
+    assert_same(got, exp)
+    return got
+
+
 def assert_same(got, exp, what=""):
     gl, gr, gd = got
     el, er, ed = exp
@@ -138,3 +145,38 @@ def test_error_reporting(matcher):
         matcher.match_pairs([(987654, 987655)])
     with pytest.raises(ValueError):
         matcher.upload(1, np.zeros((4, 64), np.float32))
+
+
+def test_unknown_engine_is_rejected(matcher):
+    import sfm_amd
+    lib = sfm_amd.library()
+    assert lib.sfm_hip_set_engine(matcher._h, 7) != 0
+    assert b"unknown engine" in lib.sfm_hip_last_error(matcher._h)
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1.0 / 512.0, 300.0, 6e4, 1e7])
+def test_descriptor_scale_does_not_change_matches(matcher, scale):
+    """The split-fp16 engine rescales every image by a power of two before splitting; values far
+    outside the fp16 range (or far below it) must give the reference's matches all the same."""
+    A, B, _ = synth.make_pair(700, 900, 300, seed=77)
+    A = (A * np.float32(scale)).astype(np.float32)
+    B = (B * np.float32(scale)).astype(np.float32)
+    check_pair(matcher, A, B, True)
+
+
+def test_images_of_very_different_scale(matcher):
+    """Each image has its own scale factor; a pair of images whose magnitudes differ by 2^20 still
+    goes through both engines exactly (nothing matches, as in the reference)."""
+    A, B, _ = synth.make_pair(300, 400, 100, seed=78)
+    B = (B * np.float32(2.0 ** 20)).astype(np.float32)
+    check_pair(matcher, A, B, True)
+
+
+def test_one_huge_element_among_tiny_rows(matcher):
+    """An image whose scale is set by a single outlier element: the other rows lose precision in
+    the split planes, the completeness bound notices, and the exact path answers."""
+    A, B, _ = synth.make_pair(600, 600, 300, seed=79)
+    A = (A * np.float32(1e-3)).astype(np.float32)
+    B = (B * np.float32(1e-3)).astype(np.float32)
+    A[17, 5] = np.float32(900.0)
+    check_pair(matcher, A, B, True)

@@ -4,7 +4,8 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/collect; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 600 python -u $R/bench.py 2>$OUT/bench.err | tee $OUT/bench.json | cut -c1-300 || exit 1
-timeout -k 10 600 python -u $R/bench.py --no-cpu-baseline --untimed-pass 2>>$OUT/bench.err > $OUT/bench_untimed_pass.json || exit 1
+timeout -k 10 600 python -u $R/bench.py --no-cpu-baseline --no-other-engine --untimed-pass 2>>$OUT/bench.err > $OUT/bench_untimed_pass.json || exit 1
+timeout -k 10 600 python -u $R/bench.py --no-cpu-baseline --no-other-engine --untimed-pass --engine f16x3 2>>$OUT/bench.err > $OUT/bench_untimed_pass_f16x3.json || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv && cat $OUT/kernel_stats.csv

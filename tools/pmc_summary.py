@@ -20,22 +20,26 @@ def main(root):
         for c in sorted(acc[name]):
             v = acc[name][c]
             print("    %-32s n=%-5d mean=%.6g" % (c, len(v), sum(v) / len(v)))
-    # HBM-side traffic of the distance kernel per launch.  rocprofv3 reports FETCH_SIZE and
-    # WRITE_SIZE in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so wide
-    # coalesced reads (all of this kernel's reads are 16 bytes per lane) count at half their size.
+    # HBM-side traffic of the distance kernel per launch, per engine (template argument 0 = fp32
+    # matrix instructions, 1 = split fp16).  rocprofv3 reports FETCH_SIZE and WRITE_SIZE in KiB; on
+    # gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so wide coalesced reads (all of this
+    # kernel's reads are 16 bytes per lane) count at half their size.
+    out = {}
     for name in acc:
         if "k_distance_topk" in name and "FETCH_SIZE" in acc[name] and "WRITE_SIZE" in acc[name]:
+            engine = "f16x3" if "<1>" in name else "f32"
             f = acc[name]["FETCH_SIZE"]
             w = acc[name]["WRITE_SIZE"]
             fetch = sum(f) / len(f) * 1024.0
             write = sum(w) / len(w) * 1024.0
-            out = {"kernel": "k_distance_topk", "launches_sampled": len(f),
-                   "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
-                   "fetch_correction": 2.0, "traffic_bytes_per_launch": 2.0 * fetch + write}
-            if len(sys.argv) > 2:
-                with open(sys.argv[2], "w") as fh:
-                    json.dump(out, fh, indent=1)
-            print("traffic", json.dumps(out))
+            out[engine] = {"kernel": name, "launches_sampled": len(f),
+                           "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
+                           "fetch_correction": 2.0, "traffic_bytes_per_launch": 2.0 * fetch + write}
+    if out:
+        if len(sys.argv) > 2:
+            with open(sys.argv[2], "w") as fh:
+                json.dump(out, fh, indent=1)
+        print("traffic", json.dumps(out))
 
 
 if __name__ == "__main__":
