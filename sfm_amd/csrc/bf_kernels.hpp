@@ -126,28 +126,44 @@ __device__ __forceinline__ void insert3(uint32_t& a, uint32_t& b, uint32_t& c, u
 }
 
 // Squared norms of the rows of one image, PAD_NORM for padding rows, the largest real norm
-// in xn[n_pad] and the largest magnitude of any element in xn[n_pad + 1].  One wave per row.
+// in xn[n_pad] and the largest magnitude of any element in xn[n_pad + 1].  One wave per row,
+// 64 rows per workgroup, one pair of atomics per workgroup.
+constexpr int NORM_ROWS_PER_BLOCK = 64;
 __global__ __launch_bounds__(256) void k_norms(const float* __restrict__ x, float* __restrict__ xn, int n,
                                                int n_pad) {
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  int l = threadIdx.x & 63;
-  if (row >= n_pad) return;
-  if (row >= n) {
-    if (l == 0) xn[row] = PAD_NORM;
-    return;
-  }
-  float2 v = reinterpret_cast<const float2*>(x + (size_t)row * DIM)[l];
-  float s = v.x * v.x + v.y * v.y;
-  float m = fmaxf(fabsf(v.x), fabsf(v.y));
+  __shared__ float wmax[4], wabs[4];
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  float big = 0.0f, mag = 0.0f;          // over this wave's real rows
+  for (int k = 0; k < NORM_ROWS_PER_BLOCK / 4; k++) {
+    const int row = blockIdx.x * NORM_ROWS_PER_BLOCK + k * 4 + wv;
+    if (row >= n_pad) break;
+    if (row >= n) {
+      if (l == 0) xn[row] = PAD_NORM;
+      continue;
+    }
+    const float2 v = reinterpret_cast<const float2*>(x + (size_t)row * DIM)[l];
+    float s = v.x * v.x + v.y * v.y;
+    float m = fmaxf(fabsf(v.x), fabsf(v.y));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o);
-    m = fmaxf(m, __shfl_xor(m, o));
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      m = fmaxf(m, __shfl_xor(m, o));
+    }
+    if (l == 0) xn[row] = s;
+    big = fmaxf(big, s);
+    mag = fmaxf(mag, m);
   }
   if (l == 0) {
-    xn[row] = s;
-    atomicMax(reinterpret_cast<unsigned int*>(xn + n_pad), __float_as_uint(s));
-    atomicMax(reinterpret_cast<unsigned int*>(xn + n_pad + 1), __float_as_uint(m));
+    wmax[wv] = big;
+    wabs[wv] = mag;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // non-negative floats order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned int*>(xn + n_pad),
+              __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+    atomicMax(reinterpret_cast<unsigned int*>(xn + n_pad + 1),
+              __float_as_uint(fmaxf(fmaxf(wabs[0], wabs[1]), fmaxf(wabs[2], wabs[3]))));
   }
 }
 
@@ -428,7 +444,9 @@ __device__ __forceinline__ void stage_columns_out(uint32_t cbaddr, __amdgpu_buff
 }
 
 #ifdef SFM_K1_STAMPS
-// Diagnostic build only (tools/k1_timing.hip): per workgroup start/end clocks.
+// Diagnostic build only (tools/k1_timing.hip): per workgroup clocks at start and end (cycle and
+// real-time counters), after the prologue, before the row merge, and at three points inside the
+// prologue (ten slots per workgroup).
 __device__ unsigned long long* g_stamps;
 #endif
 
@@ -438,8 +456,8 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   __shared__ __attribute__((aligned(1024))) char smem[LDS_TOTAL];
 #ifdef SFM_K1_STAMPS
   if (threadIdx.x == 0) {
-    g_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-    g_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    g_stamps[10 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    g_stamps[10 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
 
@@ -466,32 +484,60 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   for (int i = 0; i < 8; i++) yvoff[i] = (uint32_t)((l >> 5) * (DIM * 4) + (((l & 31) ^ ((2 * i + (l >> 5)) & 15)) << 4));
   constexpr auto PIECES = std::make_integer_sequence<int, 16>{};
 
-  // first stage on its way before anything else
-  stage_load(PIECES, ysrc, smem, w, yvoff, (uint32_t)(w * 16 * 1024));
-
   // A operands of the wave's two row tiles, scaled by -2 (exact): 2 x 16 x 16 bytes per lane,
-  // piece 2s + h of the lane's row for s < 16 (fp32 values, or fp16 pairs of the split planes)
+  // piece 2s + h of the lane's row for s < 16 (fp32 values, or fp16 pairs of the split planes).
+  // A lane reading its own row from memory touches 64 different cache lines per instruction, so
+  // the block's 256 rows take the same route as the columns instead: LDS-DMA in whole rows into
+  // the two (still unused) stage buffers, then conflict-free 16-byte LDS reads.
   f32x4 a0[16], a1[16];
   float sigma = 1.0f;   // ENGINE_F16X3: the accumulators hold distances times 2^(ex + ey)
-  if constexpr (ENGINE == ENGINE_F32) {
-    const f32x4* xr0 = reinterpret_cast<const f32x4*>(P.x + (size_t)(blk.row0 + 64 * w + r) * DIM);
-    const f32x4* xr1 = xr0 + 32 * (DIM / 4);
+  {
+    const char* xrows = ENGINE == ENGINE_F32 ? reinterpret_cast<const char*>(P.x) : reinterpret_cast<const char*>(P.xh);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(xrows + (size_t)blk.row0 * DIM * 4), 0, BM * DIM * 4, 0x00020000);
+    stage_load(PIECES, xsrc, smem, w, yvoff, (uint32_t)(w * 16 * 1024));
+    stage_load(PIECES, xsrc, smem + LDS_STAGE_BYTES, w, yvoff, (uint32_t)(LDS_STAGE_BYTES + w * 16 * 1024));
+#ifdef SFM_K1_STAMPS
+    if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 6] = __builtin_amdgcn_s_memtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#ifdef SFM_K1_STAMPS
+    if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 7] = __builtin_amdgcn_s_memtime();
+#endif
+    // row 64w + 32t + r of the block sits 32 KiB * w + 16 KiB * t + 512 r into the two buffers
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)(w * 32768 + r * (DIM * 4));
+    const int c0 = h ^ (r & 15);
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 #pragma unroll
     for (int s = 0; s < 16; s++) {
-      a0[s] = -2.0f * xr0[2 * s + h];
-      a1[s] = -2.0f * xr1[2 * s + h];
+      const uint32_t at = base + (uint32_t)((((c0 ^ (2 * s)) & 15) << 4) + (s >> 3) * 256);
+      a0[s] = *(const lds_f32x4*)at;
+      a1[s] = *(const lds_f32x4*)(at + 16384);
     }
-  } else {
-    const f32x4* xr0 = reinterpret_cast<const f32x4*>(P.xh + (size_t)(blk.row0 + 64 * w + r) * 256);
-    const f32x4* xr1 = xr0 + 32 * (DIM / 4);
-    const f16x8 m2 = {-2, -2, -2, -2, -2, -2, -2, -2};
+    if constexpr (ENGINE == ENGINE_F32) {
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
-      a0[s] = __builtin_bit_cast(f32x4, __builtin_bit_cast(f16x8, xr0[2 * s + h]) * m2);
-      a1[s] = __builtin_bit_cast(f32x4, __builtin_bit_cast(f16x8, xr1[2 * s + h]) * m2);
+      for (int s = 0; s < 16; s++) {
+        a0[s] = -2.0f * a0[s];
+        a1[s] = -2.0f * a1[s];
+      }
+    } else {
+      const f16x8 m2 = {-2, -2, -2, -2, -2, -2, -2, -2};
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        a0[s] = __builtin_bit_cast(f32x4, __builtin_bit_cast(f16x8, a0[s]) * m2);
+        a1[s] = __builtin_bit_cast(f32x4, __builtin_bit_cast(f16x8, a1[s]) * m2);
+      }
+      sigma = P.xscale[0] * P.yscale[0];
     }
-    sigma = P.xscale[0] * P.yscale[0];
+    __syncthreads();   // everyone has its rows: the buffers may take the first column stages
+#ifdef SFM_K1_STAMPS
+    if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 8] = __builtin_amdgcn_s_memtime();
+#endif
   }
+  // first column stage on its way
+  stage_load(PIECES, ysrc, smem, w, yvoff, (uint32_t)(w * 16 * 1024));
+
   // Park the A operands in the accumulator half of the register file: only matrix instructions
   // read them (their sources may be AGPRs), which leaves the vector half to the lists and
   // accumulators that the epilogue's vector instructions work on.
@@ -545,6 +591,9 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // stage 0 landed
+#ifdef SFM_K1_STAMPS
+  if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 4] = __builtin_amdgcn_s_memtime();
+#endif
 
   // Chunks hold a multiple of 256 columns, so stages come in pairs and each stage body is
   // compiled for a fixed LDS buffer.
@@ -589,6 +638,9 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     stage_columns_out(colbuf_addr + ((nstages - 1) & 1) * LDS_COLBUF_WORDS * 4, coldst, colvoff,
                       (uint32_t)((nstages - 1) * SN * 4), plane_bytes);
 
+#ifdef SFM_K1_STAMPS
+  if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
+#endif
   // row lists: through LDS (the stage buffers are free now), one thread per row
   uint32_t* rowbuf = reinterpret_cast<uint32_t*>(smem);
 #pragma unroll
@@ -640,8 +692,8 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 #ifdef SFM_K1_STAMPS
   __syncthreads();
   if (threadIdx.x == 0) {
-    g_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-    g_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    g_stamps[10 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    g_stamps[10 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
 }

@@ -309,7 +309,7 @@ int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descri
     e = hipMemsetAsync(im.d + (size_t)n * DIM, 0, (size_t)(im.n_pad - n) * row_bytes, up);
   if (e == hipSuccess) e = hipMemsetAsync(im.norms + im.n_pad, 0, 2 * sizeof(float), up);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_norms, dim3((im.n_pad + 3) / 4), dim3(256), 0, up, im.d, im.norms, n, im.n_pad);
+    hipLaunchKernelGGL(k_norms, dim3((im.n_pad + NORM_ROWS_PER_BLOCK - 1) / NORM_ROWS_PER_BLOCK), dim3(256), 0, up, im.d, im.norms, n, im.n_pad);
     e = hipGetLastError();
   }
   if (e == hipSuccess) {
