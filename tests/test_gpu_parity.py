@@ -180,3 +180,48 @@ def test_one_huge_element_among_tiny_rows(matcher):
     B = (B * np.float32(1e-3)).astype(np.float32)
     A[17, 5] = np.float32(900.0)
     check_pair(matcher, A, B, True)
+
+
+@pytest.mark.parametrize("na,nb,planted", [(8192, 8192, 4096), (16384, 16384, 6000)])
+def test_full_size_pairs_match_oracle(matcher, na, nb, planted):
+    """The headline sizes (BASELINE.json configs 1 and 4), index lists and distance bits."""
+    A, B, truth = synth.make_pair(na, nb, planted, seed=2024)
+    l, r, d = check_pair(matcher, A, B, True)
+    found = set(zip(l.tolist(), r.tolist()))
+    assert set(map(tuple, truth.tolist())) <= found          # every planted correspondence survives
+    assert l.tolist() == sorted(l.tolist())                  # brute_force_matcher.cc:16: ascending lhs
+
+
+@pytest.mark.parametrize("na,nb,planted", [(300, 40000, 200), (5000, 20000, 2500), (20000, 700, 500)])
+def test_more_columns_than_one_chunk_holds(matcher, na, nb, planted):
+    """Second images beyond 16384 rows are cut into several column chunks per row block; first
+    images beyond 256 rows into several row blocks: the merged lists must still give the
+    reference's answer."""
+    A, B, _ = synth.make_pair(na, nb, planted, seed=31 + na)
+    check_pair(matcher, A, B, True)
+    check_pair(matcher, A, B, False)
+
+
+def test_swapped_pair_is_the_mirror_image(matcher):
+    """Cross-checked matches of (A, B) and (B, A) mirror each other, except for the reference's
+    map_[j] quirk, which can only add matches whose lhs index is 0 (brute_force_matcher.cc:75-78)."""
+    A, B, _ = synth.make_pair(3000, 2500, 1200, seed=99)
+    l, r, _ = run_pair(matcher, A, B, 0.8, True)
+    l2, r2, _ = run_pair(matcher, B, A, 0.8, True)
+    ab = {(i, j) for i, j in zip(l.tolist(), r.tolist()) if i != 0}
+    ba = {(j, i) for i, j in zip(l2.tolist(), r2.tolist()) if i != 0}
+    assert {p for p in ab if p[1] != 0} == {p for p in ba if p[0] != 0}
+
+
+def test_ragged_batch_in_one_call(matcher):
+    """Pairs of very different sizes (and an empty image) in a single sfm_hip_match_pairs call."""
+    sizes = [0, 1, 255, 256, 257, 1000, 3000]
+    base = synth.make_image_set(len(sizes), max(sizes), 0.6, seed=500)
+    imgs = [np.ascontiguousarray(base[k][:n]) for k, n in enumerate(sizes)]
+    for k, im in enumerate(imgs):
+        matcher.upload(100 + k, im)
+    pairs = [(100 + a, 100 + b) for a in range(len(sizes)) for b in range(a + 1, len(sizes))]
+    res = matcher.match_pairs(pairs, 0.8, True)
+    for (a, b), got in zip(pairs, res):
+        exp = oracle.match_pair(imgs[a - 100], imgs[b - 100], 0.8, True, threads=4)
+        assert_same(got, exp, "pair %s" % ((a, b),))
