@@ -47,6 +47,36 @@ def cpu_baseline(A, B, expected):
             "all_cores": {"value": 1.0 / t16, "cores": 16, "seconds_per_pair": t16}}
 
 
+def replication_check(m, rank, world, local_rank, barrier, n_images=64):
+    """Outside the timed region, N > 1 only: how long it takes to give every GPU a descriptor set
+    of n_images x 8192 rows (i) by uploading everything from each rank's host memory and (ii) by
+    uploading each rank's share and all-gathering over RCCL/xGMI.  Reported, never fatal."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sfm_amd.distributed import replicate_images, shard_bounds
+    try:
+        rng = np.random.default_rng(7)
+        ids = list(range(1000, 1000 + n_images))
+        images = {i: rng.random((N_FEATURES, 128), dtype=np.float32) for i in ids}
+        lo, hi = shard_bounds(len(ids), rank, world)
+        mine = {i: images[i] for i in ids[lo:hi]}
+        out = {"images": n_images, "rows_per_image": N_FEATURES, "bytes": n_images * N_FEATURES * 512}
+        for name, method, src in (("host_uploads_s", "host", images), ("collective_s", "collective", mine)):
+            barrier()
+            t0 = time.perf_counter()
+            replicate_images(m, src, rank, world, device=torch.device("cuda", local_rank), method=method)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            out[name] = float(tt.item())
+            for i in ids:
+                m.drop(i)
+        return out
+    except Exception as e:   # a report, not a gate
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def roofline(st, engine, traffic):
     """Distance kernel against the matrix-instruction peak of the type it multiplies in.
 
@@ -81,6 +111,9 @@ def main():
                     help="how the distance kernel forms its products (include/sfm_hip.h)")
     ap.add_argument("--no-other-engine", action="store_true",
                     help="do not time the library's other distance engine after the main run")
+    ap.add_argument("--replication-check", action="store_true",
+                    help="N > 1: also time host uploads against the RCCL all-gather of a descriptor set "
+                         "(outside the timed region; adds collectives to the run, hence opt-in)")
     ap.add_argument("--untimed-pass", action="store_true",
                     help="after the timed region, run the same K steps once more without per-launch kernel "
                          "timing and report that rate as an extra field")
@@ -152,6 +185,10 @@ def main():
             m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
         m.sync()
         free_rate = args.steps * args.pairs_per_step / (time.perf_counter() - t1)
+    replication = None
+    if dist_on and args.replication_check:
+        replication = replication_check(m, rank, world, local_rank, barrier)
+
     cnt = int(out[0][0])
     got = (out[1][0, :cnt].astype(np.int64), out[2][0, :cnt].astype(np.int64))
 
@@ -188,6 +225,8 @@ def main():
             "pairs_per_s_this_gpu_without_kernel_timing": free_rate,
             "roofline": roof,
         }
+        if replication is not None:
+            line["replication"] = replication
         if world == 1 and not args.no_other_engine:
             # the library's other distance engine on the same steps (its own timed region)
             other = "f16x3" if args.engine == "f32" else "f32"

@@ -73,6 +73,12 @@ const char* sfm_hip_last_error(const sfm_hip_ctx* ctx);
  * replaces the previous data.  n may be 0.  Blocking. */
 int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n);
 
+/* The same, from descriptors that already lie in the memory of the context's device (for a
+ * descriptor set that reached the GPU over xGMI from another GPU instead of from the host; the
+ * reference has no counterpart: its images only ever live in host memory).  The source must not be
+ * written while the call runs; it is not needed afterwards.  Blocking. */
+int sfm_hip_upload_image_device(sfm_hip_ctx* ctx, int64_t image_id, const float* device_descriptors, int32_t n);
+
 /* Forget one image / all images and free their device memory. */
 int sfm_hip_drop_image(sfm_hip_ctx* ctx, int64_t image_id);
 int sfm_hip_drop_all_images(sfm_hip_ctx* ctx);

@@ -14,6 +14,7 @@ EXPORTS = (
     "sfm_hip_upload_image", "sfm_hip_drop_image", "sfm_hip_drop_all_images", "sfm_hip_image_size",
     "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
     "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats", "sfm_hip_set_engine",
+    "sfm_hip_upload_image_device",
 )
 
 
@@ -56,6 +57,7 @@ def library():
     lib.sfm_hip_last_error.argtypes = [vp]
     lib.sfm_hip_last_error.restype = ctypes.c_char_p
     lib.sfm_hip_upload_image.argtypes = [vp, i64, vp, i32]
+    lib.sfm_hip_upload_image_device.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int32]
     lib.sfm_hip_drop_image.argtypes = [vp, i64]
     lib.sfm_hip_drop_all_images.argtypes = [vp]
     lib.sfm_hip_image_size.argtypes = [vp, i64, ctypes.POINTER(i32)]
@@ -131,6 +133,11 @@ class Matcher:
             raise ValueError("descriptors must be [n, 128]")
         self._check(self._lib.sfm_hip_upload_image(self._h, int(image_id), d.ctypes.data, d.shape[0]),
                     "sfm_hip_upload_image")
+
+    def upload_device(self, image_id, device_ptr, n):
+        """Register n descriptors (rows of 128 floats) that already lie in this GPU's memory."""
+        self._check(self._lib.sfm_hip_upload_image_device(self._h, int(image_id), int(device_ptr), int(n)),
+                    "sfm_hip_upload_image_device")
 
     def drop(self, image_id):
         self._check(self._lib.sfm_hip_drop_image(self._h, int(image_id)), "sfm_hip_drop_image")

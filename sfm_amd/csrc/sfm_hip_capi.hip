@@ -278,7 +278,8 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
 
 const char* sfm_hip_last_error(const sfm_hip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
 
-int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n) {
+namespace {
+int upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n, hipMemcpyKind kind) {
   if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
   if (n < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative descriptor count");
   if (n > 0 && !descriptors) return fail(ctx, SFM_HIP_ERR_INVALID, "descriptors is null");
@@ -304,7 +305,7 @@ int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descri
     return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc image planes: ") + hipGetErrorString(e));
   }
   e = hipSuccess;
-  if (n > 0) e = hipMemcpyAsync(im.d, descriptors, (size_t)n * row_bytes, hipMemcpyHostToDevice, up);
+  if (n > 0) e = hipMemcpyAsync(im.d, descriptors, (size_t)n * row_bytes, kind, up);
   if (e == hipSuccess && im.n_pad > n)
     e = hipMemsetAsync(im.d + (size_t)n * DIM, 0, (size_t)(im.n_pad - n) * row_bytes, up);
   if (e == hipSuccess) e = hipMemsetAsync(im.norms + im.n_pad, 0, 2 * sizeof(float), up);
@@ -324,6 +325,15 @@ int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descri
   }
   ctx->images[image_id] = im;
   return SFM_HIP_OK;
+}
+}  // namespace
+
+int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n) {
+  return upload_image(ctx, image_id, descriptors, n, hipMemcpyHostToDevice);
+}
+
+int sfm_hip_upload_image_device(sfm_hip_ctx* ctx, int64_t image_id, const float* device_descriptors, int32_t n) {
+  return upload_image(ctx, image_id, device_descriptors, n, hipMemcpyDeviceToDevice);
 }
 
 int sfm_hip_drop_image(sfm_hip_ctx* ctx, int64_t image_id) {

@@ -67,3 +67,48 @@ def test_two_ranks_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARDING_OK" in outs[0]
+
+
+REPLICATE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+from sfm_amd import synth
+from sfm_amd.distributed import replicate_images, shard_bounds
+
+class Recorder:                 # stands in for the GPU context: remembers what was uploaded
+    def __init__(self): self.images = {}
+    def upload(self, image_id, rows): self.images[int(image_id)] = np.array(rows, dtype=np.float32, copy=True)
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+sizes = (160, 0, 129, 64, 1)
+full = {10 + i: im[:n] for i, (im, n) in enumerate(zip(synth.make_image_set(5, 160, 0.5, seed=22), sizes))}
+ids = sorted(full)
+lo, hi = shard_bounds(len(ids), rank, world)
+mine = {i: full[i] for i in ids[lo:hi]}          # each rank holds only its share
+rec = Recorder()
+rows = replicate_images(rec, mine, rank, world, method="collective")
+assert rows == sum(sizes)
+assert sorted(rec.images) == ids
+for i in ids:
+    assert rec.images[i].shape == full[i].shape and np.array_equal(rec.images[i], full[i]), i
+host = Recorder()
+assert replicate_images(host, full, rank, world, method="host") == sum(sizes)
+assert all(np.array_equal(host.images[i], full[i]) for i in ids)
+print("REPLICATE_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_replication_collective_two_ranks_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(REPLICATE_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("REPLICATE_OK" in o for o in outs)
