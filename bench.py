@@ -127,7 +127,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    # SFM_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL group, barriers, max over ranks)
+    # even with one rank: a rehearsal for machines with a single GPU
+    dist_on = world > 1 or os.environ.get("SFM_BENCH_FORCE_DIST") == "1"
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
