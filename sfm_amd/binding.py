@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libsfm_hip.so")
+# SFM_HIP_LIBRARY names another build of the same library (A/B timing of two builds)
+_LIB_PATH = os.environ.get("SFM_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libsfm_hip.so")
 
 ENGINES = {"f32": 0, "f16x3": 1}
 

@@ -322,9 +322,22 @@ __device__ __forceinline__ void anchor16(uint32_t (&x)[16]) {
 //   ENGINE_F32:   four k-steps of v_mfma_f32_32x32x2_f32 per row tile;
 //   ENGINE_F16X3: even S = high halves of k-slab S/2: products with the high and the low halves of A;
 //                 odd S = low halves of the slab: product with the high halves of A.
-template <int ENGINE, int TOFF, int S, int ROT, bool HAS_NEXT>
+// What a step needs to send one 1 KiB piece of the NEXT column stage on its way (LDS-DMA).  The
+// pieces of a stage are spread over the steps of the current stage, one every fourth step: issued
+// in one burst they fill the memory pipeline's queue (LDS-DMA moves ~45 bytes per clock per
+// compute unit) and every wave sits at its next memory instruction until the queue drains.
+struct StageFeed {
+  __amdgpu_buffer_rsrc_t src;
+  char* ldsbuf;          // the buffer the current stage does not read
+  uint32_t sbase;        // byte offset of this wave's share of the next stage in the chunk; past the
+                         // chunk's end for the last stage, where the loads return nothing
+  int w;
+};
+
+template <int ENGINE, int TOFF, int S, int ROT, bool HAS_NEXT, int PIECE>
 __device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const f32x4 (&a0)[16], const f32x4 (&a1)[16],
-                                          f32x4 (&b)[3], const uint32_t (&X)[8]) {
+                                          f32x4 (&b)[3], const uint32_t (&X)[8], const StageFeed& feed,
+                                          const uint32_t (&yvoff)[8]) {
   if constexpr (S + 2 < 16) {
     lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(S + 2 + ROT) % 3], X[(S + 2) & 7]);
     lds_wait<2>();
@@ -356,14 +369,20 @@ __device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const f32x
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S - 1]), bh, acc1, 0, 0, 0);
     }
   }
+#ifndef SFM_ABLATE_GLDS
+  if constexpr (PIECE >= 0) stage_load_piece<PIECE>(feed.src, feed.ldsbuf, feed.w, yvoff, feed.sbase);
+#endif
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int ENGINE, int TOFF, int ROT, bool HAS_NEXT, int... S>
+template <int ENGINE, int TOFF, int ROT, bool HAS_NEXT, int CT, int... S>
 __device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32x16& acc0, f32x16& acc1,
                                            const f32x4 (&a0)[16], const f32x4 (&a1)[16], f32x4 (&b)[3],
-                                           const uint32_t (&X)[8]) {
-  (pair_step<ENGINE, TOFF, S, ROT, HAS_NEXT>(acc0, acc1, a0, a1, b, X), ...);
+                                           const uint32_t (&X)[8], const StageFeed& feed,
+                                           const uint32_t (&yvoff)[8]) {
+  // piece 4 CT + S/4 of the next stage leaves with step S = 1, 5, 9, 13 of column tile CT
+  (pair_step<ENGINE, TOFF, S, ROT, HAS_NEXT, (S % 4 == 1 ? 4 * CT + S / 4 : -1)>(acc0, acc1, a0, a1, b, X, feed, yvoff),
+   ...);
 }
 
 // Fold one finished accumulator tile into the lane's row lists and column list.
@@ -385,7 +404,8 @@ __device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLi
 template <int ENGINE, int CT>
 __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
                                           f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tv, LaneLists& L0,
-                                          LaneLists& L1, uint32_t lowc, int h, uint32_t* cb) {
+                                          LaneLists& L1, uint32_t lowc, int h, uint32_t* cb, const StageFeed& feed,
+                                          const uint32_t (&yvoff)[8]) {
   constexpr int TOFF = CT * 32 * DIM * 4;
   if constexpr (CT == 0) {
     lds_read16<TOFF>(b[0], X[0]);
@@ -396,7 +416,8 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
   for (int i = 0; i < 16; i++) zero[i] = 0.0f;
   f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
   f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
-  pair_steps<ENGINE, TOFF, CT % 3, (CT < 3)>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X);
+  pair_steps<ENGINE, TOFF, CT % 3, (CT < 3), CT>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X, feed,
+                                                 yvoff);
 
   uint32_t cl0 = SENT, cl1 = SENT, cl2 = SENT;
 #ifdef SFM_ABLATE_FOLD
@@ -576,10 +597,15 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
       X1[k] = X0[k] + LDS_STAGE_BYTES;
     }
   }
-  const float* ynp = P.yn + blk.col0 + r;
+  // Column norms through a buffer descriptor as well: a load through a generic pointer would be a
+  // FLAT instruction, which also counts in the LDS counter that the hand-counted waits below use
+  // (every wait would then sit out a trip to memory).
+  const __amdgpu_buffer_rsrc_t ynsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(P.yn + blk.col0), 0, blk.ncols * 4, 0x00020000);
   float nbn[4];
 #pragma unroll
-  for (int ct = 0; ct < 4; ct++) nbn[ct] = ynp[32 * ct];
+  for (int ct = 0; ct < 4; ct++)
+    nbn[ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ynsrc, (r + 32 * ct) * 4, 0, 0));
   // this row block's column lists for the chunk's columns: three planes of nb_pad words
   const uint32_t plane_bytes = (uint32_t)P.nb_pad * 4u;
   const __amdgpu_buffer_rsrc_t coldst = __builtin_amdgcn_make_buffer_rsrc(
@@ -602,13 +628,13 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     float bn[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ct++) bn[ct] = h == 0 ? 1.0f : scaled_norm(nbn[ct]);
+    // the next stage's columns leave piece by piece during this stage (past the last stage the
+    // offsets lie beyond the descriptor's range: those loads fetch nothing)
+    const StageFeed feed{ysrc, smem + (u ^ 1) * LDS_STAGE_BYTES, (uint32_t)((gg + 1) * LDS_STAGE_BYTES + w * 16 * 1024), w};
     if (gg + 1 < nstages) {
-#ifndef SFM_ABLATE_GLDS
-      stage_load(PIECES, ysrc, smem + (u ^ 1) * LDS_STAGE_BYTES, w, yvoff,
-                 (uint32_t)((gg + 1) * LDS_STAGE_BYTES + w * 16 * 1024));
-#endif
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) nbn[ct] = ynp[(gg + 1) * SN + 32 * ct];
+      for (int ct = 0; ct < 4; ct++)
+        nbn[ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ynsrc, (r + 32 * ct) * 4, (gg + 1) * SN * 4, 0));
     }
     // column lists of the previous stage: each wave merges and stores 32 of its 128 columns
     if (gg >= 1 && h == 0)
@@ -619,10 +645,10 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 3) * 32 + r;
     f32x4 b[3];
     const uint32_t (&X)[8] = u == 0 ? X0 : X1;
-    tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 96);
-    tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 96);
-    tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 96);
-    tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 96);
+    tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 96, feed, yvoff);
+    tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 96, feed, yvoff);
+    tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 96, feed, yvoff);
+    tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 96, feed, yvoff);
     // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
     // compiler does not always drain it for __syncthreads(), so wait explicitly.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
