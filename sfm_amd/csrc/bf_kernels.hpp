@@ -681,38 +681,49 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   {
     // Row tid: 32 sorted triples.  The five smallest keys of all 96 come from the lists whose
     // head is among the five smallest heads, so rank the heads first and then add the tails of
-    // those five lists only.
+    // those five lists only.  While ranking, a key carries (lane, entry) in its low bits in place
+    // of the tile number, so that five v_med3/v_min per insertion suffice (no index to drag
+    // along); the winners' full keys are read back from LDS afterwards.
     const uint32_t* src = rowbuf + tid * ROWBUF_STRIDE;
-    Top5 t5;
-    top5_init(t5);
+    uint32_t m0 = SENT, m1 = SENT, m2 = SENT, m3 = SENT, m4 = SENT;
+    auto put = [&](uint32_t x) {
+      m4 = med3u(m3, m4, x);
+      m3 = med3u(m2, m3, x);
+      m2 = med3u(m1, m2, x);
+      m1 = med3u(m0, m1, x);
+      m0 = m0 < x ? m0 : x;
+    };
     uint32_t lanebound = SENT;
 #pragma unroll 8
     for (int p = 0; p < 32; p++) {
-      top5_put(t5, src[p * 3], (uint32_t)p);
+      put((src[p * 3] & ROW_MASK) | (uint32_t)p);
       const uint32_t k2 = src[p * 3 + 2];
       lanebound = lanebound < k2 ? lanebound : k2;
     }
-    const uint32_t hp[5] = {t5.i0, t5.i1, t5.i2, t5.i3, t5.i4};
-    const uint32_t hv[5] = {t5.v0, t5.v1, t5.v2, t5.v3, t5.v4};
+    const uint32_t hp[5] = {m0 & 31u, m1 & 31u, m2 & 31u, m3 & 31u, m4 & 31u};
 #pragma unroll
     for (int e = 0; e < 5; e++) {
-      const uint32_t k1 = hv[e] == SENT ? SENT : src[hp[e] * 3 + 1];
-      const uint32_t k2 = hv[e] == SENT ? SENT : src[hp[e] * 3 + 2];
-      top5_put(t5, k1, hp[e]);
-      top5_put(t5, k2, hp[e]);
+      put((src[hp[e] * 3 + 1] & ROW_MASK) | hp[e] | 32u);
+      put((src[hp[e] * 3 + 2] & ROW_MASK) | hp[e] | 64u);
     }
-    const uint32_t bound = lanebound < t5.v4 ? lanebound : t5.v4;
+    // low bits of a ranked key: lane (5 bits), entry in that lane's triple (2 bits)
+    const uint32_t mk[4] = {m0, m1, m2, m3};
+    uint32_t fullkey[4], lane[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      lane[e] = mk[e] & 31u;
+      fullkey[e] = src[lane[e] * 3 + ((mk[e] >> 5) & 3u)];
+    }
+    const uint32_t fifth = m4 == SENT ? SENT : (m4 & ROW_MASK);   // value bits only: never above the real key
+    const uint32_t bound = lanebound < fifth ? lanebound : fifth;
     uint32_t* dst = P.rowpart + (size_t)blk.chunk * ROWPART_FIELDS * P.na_pad + blk.row0 + tid;
     const size_t st = (size_t)P.na_pad;
     const uint32_t c0 = (uint32_t)blk.col0;
-    dst[0 * st] = t5.v0;
-    dst[1 * st] = t5.v1;
-    dst[2 * st] = t5.v2;
-    dst[3 * st] = t5.v3;
-    dst[4 * st] = c0 + ((t5.v0 & ROW_LOW) << 5) + t5.i0;
-    dst[5 * st] = c0 + ((t5.v1 & ROW_LOW) << 5) + t5.i1;
-    dst[6 * st] = c0 + ((t5.v2 & ROW_LOW) << 5) + t5.i2;
-    dst[7 * st] = c0 + ((t5.v3 & ROW_LOW) << 5) + t5.i3;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      dst[e * st] = fullkey[e];
+      dst[(4 + e) * st] = c0 + ((fullkey[e] & ROW_LOW) << 5) + lane[e];
+    }
     dst[8 * st] = bound;
   }
 #ifdef SFM_K1_STAMPS
