@@ -93,8 +93,11 @@ struct BlockDev {
   int32_t col0;      // first column of the chunk
   int32_t ncols;     // columns in the chunk (multiple of SN)
   int32_t chunk;     // chunk number (selects the row-partial slab)
-  int32_t pad_[3];
+  int32_t pad_;
+  const void* xrows; // first of the block's 256 rows in the form the engine multiplies (512 bytes each):
+                     // known one dependent load earlier than anything reached through the pair table
 };
+static_assert(sizeof(BlockDev) == 32, "BlockDev is uploaded as a packed table");
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -483,21 +486,12 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 #endif
 
   const BlockDev blk = blocks[blockIdx.x];
-  const PairDev& P = pairs[blk.pair];
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
   const int r = l & 31;
   const int h = l >> 5;
 
-  uint32_t* colbuf = reinterpret_cast<uint32_t*>(smem + LDS_OFF_COLBUF);
-
-  const int nstages = blk.ncols / SN;
-  // the chunk's columns as a raw buffer (0x00020000: 32-bit raw data format)
-  // (both engines stream 512-byte rows: 128 floats, or 128 + 128 halves)
-  const char* yrows = ENGINE == ENGINE_F32 ? reinterpret_cast<const char*>(P.y) : reinterpret_cast<const char*>(P.yh);
-  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(yrows + (size_t)blk.col0 * DIM * 4), 0, blk.ncols * DIM * 4, 0x00020000);
   // byte offset of this lane inside piece i of a stage (piece = 2 rows): row parity, then the
   // 16-byte chunk position XOR-swizzled by the row number
   uint32_t yvoff[8];
@@ -509,15 +503,30 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   // piece 2s + h of the lane's row for s < 16 (fp32 values, or fp16 pairs of the split planes).
   // A lane reading its own row from memory touches 64 different cache lines per instruction, so
   // the block's 256 rows take the same route as the columns instead: LDS-DMA in whole rows into
-  // the two (still unused) stage buffers, then conflict-free 16-byte LDS reads.
+  // the two (still unused) stage buffers, then conflict-free 16-byte LDS reads.  The rows'
+  // address comes with the block descriptor, so the transfer is on its way before the pair table
+  // (one more dependent scalar load) has been read.
+  {
+    const __amdgpu_buffer_rsrc_t xsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(blk.xrows), 0, BM * DIM * 4, 0x00020000);
+    stage_load(PIECES, xsrc, smem, w, yvoff, (uint32_t)(w * 16 * 1024));
+    stage_load(PIECES, xsrc, smem + LDS_STAGE_BYTES, w, yvoff, (uint32_t)(LDS_STAGE_BYTES + w * 16 * 1024));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  const PairDev& P = pairs[blk.pair];
+  uint32_t* colbuf = reinterpret_cast<uint32_t*>(smem + LDS_OFF_COLBUF);
+
+  const int nstages = blk.ncols / SN;
+  // the chunk's columns as a raw buffer (0x00020000: 32-bit raw data format)
+  // (both engines stream 512-byte rows: 128 floats, or 128 + 128 halves)
+  const char* yrows = ENGINE == ENGINE_F32 ? reinterpret_cast<const char*>(P.y) : reinterpret_cast<const char*>(P.yh);
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(yrows + (size_t)blk.col0 * DIM * 4), 0, blk.ncols * DIM * 4, 0x00020000);
+
   f32x4 a0[16], a1[16];
   float sigma = 1.0f;   // ENGINE_F16X3: the accumulators hold distances times 2^(ex + ey)
   {
-    const char* xrows = ENGINE == ENGINE_F32 ? reinterpret_cast<const char*>(P.x) : reinterpret_cast<const char*>(P.xh);
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(xrows + (size_t)blk.row0 * DIM * 4), 0, BM * DIM * 4, 0x00020000);
-    stage_load(PIECES, xsrc, smem, w, yvoff, (uint32_t)(w * 16 * 1024));
-    stage_load(PIECES, xsrc, smem + LDS_STAGE_BYTES, w, yvoff, (uint32_t)(LDS_STAGE_BYTES + w * 16 * 1024));
 #ifdef SFM_K1_STAMPS
     if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 6] = __builtin_amdgcn_s_memtime();
 #endif

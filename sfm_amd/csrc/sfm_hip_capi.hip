@@ -516,6 +516,9 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
             b.col0 = col0;
             b.ncols = ncols;
             b.chunk = c;
+            b.xrows = ctx->engine == SFM_HIP_ENGINE_F16X3
+                          ? (const void*)(pl.X->split + (size_t)rb * BM * 256)
+                          : (const void*)(pl.X->d + (size_t)rb * BM * DIM);
           }
         }
         flop += 2.0 * pl.X->n * (double)pl.Y->n * DIM;

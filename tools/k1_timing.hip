@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   P.na = na; P.nb = nb; P.na_pad = na_pad; P.nb_pad = nb_pad; P.nchunks = nchunks; P.chunk_cols = chunk;
   std::vector<BlockDev> blocks;
   for (int c = 0; c < nchunks; c++) for (int rb = 0; rb < nrb; rb++) {
-    BlockDev b{}; b.pair = 0; b.row0 = rb * BM; b.col0 = c * chunk; b.ncols = std::min(chunk, nb_pad - c * chunk); b.chunk = c; blocks.push_back(b);
+    BlockDev b{}; b.pair = 0; b.row0 = rb * BM; b.col0 = c * chunk; b.ncols = std::min(chunk, nb_pad - c * chunk); b.chunk = c; b.xrows = engine ? (const void*)(hx + (size_t)rb * BM * 256) : (const void*)(dx + (size_t)rb * BM * DIM); blocks.push_back(b);
   }
   PairDev* dP; BlockDev* dB; unsigned long long* dS;
   size_t nblk = blocks.size();
