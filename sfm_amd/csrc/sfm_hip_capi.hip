@@ -3,6 +3,7 @@
 #include "../../include/sfm_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -52,8 +53,7 @@ struct Lane {
   size_t stage_bytes[2] = {0, 0};
   hipEvent_t stage_free[2] = {nullptr, nullptr};
   int stage_slot = 0;
-  hipEvent_t distance_done = nullptr;   // recorded after this lane's latest distance kernel
-  bool distance_recorded = false;
+  hipEvent_t last_distance_stop = nullptr;   // stop event of this lane's latest timed distance kernel
 };
 
 constexpr int N_LANES = 2;
@@ -181,6 +181,7 @@ int fold_timed(sfm_hip_ctx* ctx) {
     ctx->event_pool.push_back(t.stop);
   }
   ctx->timed.clear();
+  for (Lane& l : ctx->lanes) l.last_distance_stop = nullptr;   // its event went back to the pool
   return SFM_HIP_OK;
 }
 
@@ -238,7 +239,6 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
   for (Lane& l : ctx->lanes) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
     for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&l.stage_free[s], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.distance_done, hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->rescanned_dev, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(ctx->rescanned_dev, 0, sizeof(unsigned long long));
@@ -264,7 +264,6 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
       if (l.stage_host[s]) (void)hipHostFree(l.stage_host[s]);
       if (l.stage_free[s]) (void)hipEventDestroy(l.stage_free[s]);
     }
-    if (l.distance_done) (void)hipEventDestroy(l.distance_done);
     if (l.stream) (void)hipStreamDestroy(l.stream);
   }
   if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
@@ -544,27 +543,26 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       // one: a launch duration only means something when launches do not share the chip.
       // (Without timing they are left free: the next launch's workgroups then take over compute
       // units one by one as the previous launch's workgroups finish, which is worth a few percent.)
-      if (ctx->profiling)
-        for (Lane& o : ctx->lanes)
-          if (&o != &L && o.distance_recorded) HIP_TRY(ctx, hipStreamWaitEvent(st, o.distance_done, 0));
-      TimedLaunch tl{};
+      // With per-launch timing the start/stop events ride on the kernel's own dispatch packet
+      // (hipExtLaunchKernelGGL): separate event records would each put a marker packet, and
+      // several microseconds, between this kernel and its neighbours.
+      void (*kernel)(const PairDev*, const BlockDev*) =
+          ctx->engine == SFM_HIP_ENGINE_F16X3 ? k_distance_topk<ENGINE_F16X3> : k_distance_topk<ENGINE_F32>;
       if (ctx->profiling) {
+        for (Lane& o : ctx->lanes)
+          if (&o != &L && o.last_distance_stop) HIP_TRY(ctx, hipStreamWaitEvent(st, o.last_distance_stop, 0));
+        TimedLaunch tl{};
         tl.start = get_event(ctx);
         tl.stop = get_event(ctx);
         tl.flop = flop;
-        HIP_TRY(ctx, hipEventRecord(tl.start, st));
-      }
-      if (ctx->engine == SFM_HIP_ENGINE_F16X3)
-        hipLaunchKernelGGL(k_distance_topk<ENGINE_F16X3>, dim3((unsigned)n_blocks), dim3(256), 0, st, dp, db);
-      else
-        hipLaunchKernelGGL(k_distance_topk<ENGINE_F32>, dim3((unsigned)n_blocks), dim3(256), 0, st, dp, db);
-      HIP_TRY(ctx, hipGetLastError());
-      if (ctx->profiling) {
-        HIP_TRY(ctx, hipEventRecord(tl.stop, st));
+        hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, tl.start, tl.stop, 0, dp, db);
+        HIP_TRY(ctx, hipGetLastError());
         ctx->timed.push_back(tl);
+        L.last_distance_stop = tl.stop;
+      } else {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, dp, db);
+        HIP_TRY(ctx, hipGetLastError());
       }
-      HIP_TRY(ctx, hipEventRecord(L.distance_done, st));
-      L.distance_recorded = true;
     }
     // Pairs with an empty image still go through the re-rank step: with no
     // candidates every query comes out unmatched, as in the reference.  Their
