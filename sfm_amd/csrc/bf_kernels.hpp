@@ -882,6 +882,11 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
   const float* obase = dir == 0 ? P.y : P.x;
   const int tid = threadIdx.x;
   if (tid == 0) n_unsafe = 0;
+  // what step C needs from memory, requested now: the query's squared norm and the largest norm
+  // on the other side
+  const float* qn_arr = dir == 0 ? P.xn : P.yn;
+  const float my_qn = (tid < RR_QUERIES && q0 + tid < nq) ? qn_arr[q0 + tid] : 0.0f;
+  const float other_max = (dir == 0 ? P.yn : P.xn)[dir == 0 ? P.nb_pad : P.na_pad];
 
   // ---- A
   {
@@ -968,11 +973,12 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
   // ---- B
   {
     const int w = tid >> 6, l = tid & 63, half = l >> 5, j = l & 31;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-      // all of the pass's row loads first (one trip to memory), then the arithmetic
-      f32x4 uq[16], vc[16];
-      uint32_t cis[16];
+    // Two passes of 128 (query, candidate) pairs.  A pass's row loads are issued as early as its
+    // registers are free -- pass 1's right after pass 0's squares went to LDS -- so that they
+    // travel while the serial sums of the previous pass run.
+    f32x4 uq[16], vc[16];
+    uint32_t cis[16];
+    auto issue_loads = [&](int pass) {
 #pragma unroll
       for (int it = 0; it < 16; it++) {
         const int pi = pass * 128 + w * 32 + it * 2 + half;
@@ -981,6 +987,10 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
         uq[it] = reinterpret_cast<const f32x4*>(qbase + (size_t)(q0 + (pi >> 2) < nq ? q0 + (pi >> 2) : q0) * DIM)[j];
         vc[it] = reinterpret_cast<const f32x4*>(obase + (size_t)cr * DIM)[j];
       }
+    };
+    issue_loads(0);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
 #pragma unroll
       for (int it = 0; it < 16; it++) {
 #pragma clang fp contract(off)
@@ -991,6 +1001,7 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
         d.x = d.x * d.x; d.y = d.y * d.y; d.z = d.z * d.z; d.w = d.w * d.w;
         if (cis[it] != SENT) *reinterpret_cast<f32x4*>(sq + pl * RR_SQ_STRIDE + 4 * j) = d;
       }
+      if (pass == 0) issue_loads(1);
       __syncthreads();
       if (tid < 128) {
 #pragma clang fp contract(off)
@@ -1027,19 +1038,16 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
         top2_add(t, sqrtf(rsq), rsq, (int32_t)ci);
       }
     }
-    const float* qn = dir == 0 ? P.xn : P.yn;
-    const float* on = dir == 0 ? P.yn : P.xn;
-    const int opad = dir == 0 ? P.nb_pad : P.na_pad;
     const uint32_t bound = bnd[tid];
     bool safe = no <= NCAND || bound == SENT;
     if (!safe) {
       const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
       if (engine == ENGINE_F32) {
-        safe = (double)t.r2 <= excluded_lower_bound(bound, mask, qn[q], on[opad]);
+        safe = (double)t.r2 <= excluded_lower_bound(bound, mask, my_qn, other_max);
       } else {
         const float sq = dir == 0 ? P.xscale[0] : P.yscale[0];
         const float so = dir == 0 ? P.yscale[0] : P.xscale[0];
-        safe = (double)t.r2 <= excluded_lower_bound_split(bound, mask, qn[q], on[opad], sq, so);
+        safe = (double)t.r2 <= excluded_lower_bound_split(bound, mask, my_qn, other_max, sq, so);
       }
     }
     const bool accept = (double)t.d1 < ratio * (double)t.d2;   // brute_force_matcher.cc:35
