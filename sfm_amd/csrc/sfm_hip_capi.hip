@@ -21,9 +21,10 @@ namespace {
 thread_local std::string g_last_error;  // failures without a context
 
 struct Image {
+  void* block = nullptr;    // one allocation holding everything below
   float* d = nullptr;       // [n_pad][128]
-  float* norms = nullptr;   // [n_pad + 2]: squared norms, then the largest norm and the largest magnitude
   uint16_t* split = nullptr;  // [n_pad][256] scaled fp16 (high, low) planes: see k_split
+  float* norms = nullptr;   // [n_pad + 2]: squared norms, then the largest norm and the largest magnitude
   float* scale = nullptr;   // {2^e, 2^-e} of the split planes
   int32_t n = 0, n_pad = 0;
 };
@@ -72,6 +73,7 @@ struct sfm_hip_ctx {
   std::vector<hipEvent_t> event_pool;
   sfm_hip_stats stats{};
 
+  hipStream_t upload_stream = nullptr;
   int n_cu = 256;                              // compute units of the device (one distance workgroup each)
   size_t batch_bytes_limit = (size_t)6 << 30;  // work space per batch
   int max_pairs_per_batch = 256;
@@ -126,10 +128,7 @@ int ensure_stage(sfm_hip_ctx* ctx, Lane& L, int slot, size_t bytes) {
 }
 
 void free_image(Image& im) {
-  if (im.d) (void)hipFree(im.d);
-  if (im.norms) (void)hipFree(im.norms);
-  if (im.split) (void)hipFree(im.split);
-  if (im.scale) (void)hipFree(im.scale);
+  if (im.block) (void)hipFree(im.block);
   im = Image();
 }
 
@@ -238,6 +237,7 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
   e = hipSetDevice(device);
   for (Lane& l : ctx->lanes) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !ctx->upload_stream) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
     for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&l.stage_free[s], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->rescanned_dev, sizeof(unsigned long long));
@@ -266,6 +266,7 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
     }
     if (l.stream) (void)hipStreamDestroy(l.stream);
   }
+  if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
   if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
   for (auto& t : ctx->timed) {
     (void)hipEventDestroy(t.start);
@@ -283,11 +284,13 @@ int upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, i
   if (n < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative descriptor count");
   if (n > 0 && !descriptors) return fail(ctx, SFM_HIP_ERR_INVALID, "descriptors is null");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // queued work may still read the image being replaced
-  if (int rc = sync_all(ctx)) return rc;
-  hipStream_t up = ctx->lanes[0].stream;
+  // Uploads have a stream of their own: a new image is copied and prepared while matching work
+  // queued earlier keeps running.  Only replacing an image has to wait for that work, which may
+  // still read the old copy.
+  hipStream_t up = ctx->upload_stream;
   auto it = ctx->images.find(image_id);
   if (it != ctx->images.end()) {
+    if (int rc = sync_all(ctx)) return rc;
     free_image(it->second);
     ctx->images.erase(it);
   }
@@ -295,14 +298,15 @@ int upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, i
   im.n = n;
   im.n_pad = (int32_t)align_up((size_t)std::max(n, 1), IMG_PAD);
   const size_t row_bytes = DIM * sizeof(float);
-  HIP_TRY(ctx, hipMalloc((void**)&im.d, (size_t)im.n_pad * row_bytes));
-  hipError_t e = hipMalloc((void**)&im.norms, ((size_t)im.n_pad + 2) * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&im.split, (size_t)im.n_pad * 256 * sizeof(uint16_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&im.scale, 2 * sizeof(float));
-  if (e != hipSuccess) {
-    free_image(im);
+  const size_t plane = (size_t)im.n_pad * row_bytes;                       // both planes have 512-byte rows
+  const size_t norms_bytes = align_up(((size_t)im.n_pad + 2) * sizeof(float), 256);
+  hipError_t e = hipMalloc(&im.block, 2 * plane + norms_bytes + 256);
+  if (e != hipSuccess)
     return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc image planes: ") + hipGetErrorString(e));
-  }
+  im.d = (float*)im.block;
+  im.split = (uint16_t*)((char*)im.block + plane);
+  im.norms = (float*)((char*)im.block + 2 * plane);
+  im.scale = (float*)((char*)im.block + 2 * plane + norms_bytes);
   e = hipSuccess;
   if (n > 0) e = hipMemcpyAsync(im.d, descriptors, (size_t)n * row_bytes, kind, up);
   if (e == hipSuccess && im.n_pad > n)

@@ -6,6 +6,7 @@
 #include <exception>
 #include <map>
 #include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -75,17 +76,34 @@ void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t 
   } guard{ctx, {}};
   if (engine >= 0 && sfm_hip_set_engine(ctx, engine) != SFM_HIP_OK) fail(ctx, "sfm_hip_set_engine");
 
-  std::map<IndexT, const Descriptors*> images;
+  // Work through the shard in the order of each pair's larger image id, not in list order: the
+  // pairs of the list's first image need every other image at once, whereas in this order the k-th
+  // new image brings k - 1 new pairs, so from a handful of images on the GPU has more to do than
+  // the uploads take.  (Where a pair's result lands does not depend on when it is computed.)
+  std::vector<size_t> order(hi - lo);
+  for (size_t k = 0; k < order.size(); k++) order[k] = lo + k;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    const IndexT ma = std::max(jobs[a].pair.first, jobs[a].pair.second);
+    const IndexT mb = std::max(jobs[b].pair.first, jobs[b].pair.second);
+    return ma < mb;
+  });
+  // An image is uploaded right before the first batch that needs it (below), while the GPU is
+  // busy with the batch before.
+  std::set<IndexT> uploaded;
   int64_t stride = 1;
-  for (size_t p = lo; p < hi; p++) {
-    images[jobs[p].pair.first] = jobs[p].first;
-    images[jobs[p].pair.second] = jobs[p].second;
-  }
-  for (const auto& [id, d] : images) {
-    if (sfm_hip_upload_image(ctx, id, d->data(), (int32_t)d->size()) != SFM_HIP_OK)
-      fail(ctx, "sfm_hip_upload_image");
-    stride = std::max<int64_t>(stride, (int64_t)d->size());
-  }
+  for (size_t p = lo; p < hi; p++) stride = std::max<int64_t>(stride, (int64_t)jobs[p].first->size());
+  auto upload_for = [&](size_t b0, size_t b1) {     // positions in 'order'
+    for (size_t q = b0; q < b1; q++) {
+      const size_t p = order[q];
+      const IndexT ids[2] = {jobs[p].pair.first, jobs[p].pair.second};
+      const Descriptors* ds[2] = {jobs[p].first, jobs[p].second};
+      for (int k = 0; k < 2; k++) {
+        if (!uploaded.insert(ids[k]).second) continue;
+        if (sfm_hip_upload_image(ctx, ids[k], ds[k]->data(), (int32_t)ds[k]->size()) != SFM_HIP_OK)
+          fail(ctx, "sfm_hip_upload_image");
+      }
+    }
+  };
 
   // batches bound the pinned result buffers (two arrays of stride ints per pair, two sets)
   const size_t batch = std::max<size_t>(1, std::min<size_t>(64, ((size_t)32 << 20) / ((size_t)stride * 8)));
@@ -105,28 +123,31 @@ void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t 
   }
   std::vector<int64_t> flat(2 * batch);
 
-  auto submit = [&](size_t b0, const Set& s) {
-    const size_t n = std::min(batch, hi - b0);
+  const size_t n_jobs = order.size();
+  auto submit = [&](size_t b0, const Set& s) {      // b0: position in 'order'
+    const size_t n = std::min(batch, n_jobs - b0);
     for (size_t k = 0; k < n; k++) {
-      flat[2 * k] = jobs[b0 + k].pair.first;
-      flat[2 * k + 1] = jobs[b0 + k].pair.second;
+      flat[2 * k] = jobs[order[b0 + k]].pair.first;
+      flat[2 * k + 1] = jobs[order[b0 + k]].pair.second;
     }
     if (sfm_hip_match_pairs(ctx, flat.data(), (int32_t)n, ratio, cross ? 1 : 0, s.counts, s.lhs, s.rhs, nullptr,
                             stride) != SFM_HIP_OK)
       fail(ctx, "sfm_hip_match_pairs");
   };
   auto collect = [&](size_t b0, const Set& s) {
-    const size_t n = std::min(batch, hi - b0);
+    const size_t n = std::min(batch, n_jobs - b0);
     for (size_t k = 0; k < n; k++) {
-      materialise(jobs[b0 + k], s.lhs + k * stride, s.rhs + k * stride, s.counts[k]);
+      materialise(jobs[order[b0 + k]], s.lhs + k * stride, s.rhs + k * stride, s.counts[k]);
       progress.pair_finished();
     }
   };
 
   size_t which = 0;
-  size_t prev = lo;
-  submit(lo, sets[which]);
-  for (size_t b0 = lo + batch; b0 < hi; b0 += batch) {
+  size_t prev = 0;
+  upload_for(0, std::min(batch, n_jobs));
+  submit(0, sets[which]);
+  for (size_t b0 = batch; b0 < n_jobs; b0 += batch) {
+    upload_for(b0, std::min(b0 + batch, n_jobs));                     // while batch 'prev' runs
     if (sfm_hip_sync(ctx) != SFM_HIP_OK) fail(ctx, "sfm_hip_sync");   // batch 'prev' is complete
     submit(b0, sets[which ^ 1]);
     collect(prev, sets[which]);
