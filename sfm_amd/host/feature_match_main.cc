@@ -1,38 +1,80 @@
-// Matching stage driver: src/feature_match_main.cc:7-33 with the GPU brute-force matcher.
-//   feature_match_main <sfm_data.bin> [--no-cross-check]
-// Load -> all pairs over the views -> Match -> Save back to the same path.  As in the
-// reference a failed Load is reported and matching goes on with whatever was loaded (nothing).
+// The matching stage as a program, with the GPU brute-force matcher:
+//
+//   feature_match_main <sfm_data.bin> [--no-cross-check] [--engine f32|f16x3] [--devices N] [--quiet]
+//
+// What it does is what src/feature_match_main.cc:7-33 does -- read the archive, pair up all views,
+// match, write the archive back in place -- and it prints the same three kinds of lines.  As in
+// the reference a failed read is reported and the stage carries on with an empty data set.
+// Exit status: 0 done, 1 usage, 2 the GPU matcher failed, 3 the archive could not be written.
 #include <cstdio>
-#include <cstring>
+#include <cstdlib>
 #include <exception>
-#include <memory>
+#include <string>
 
-#include "exhaustive_pair_builder.hpp"
 #include "hip_brute_force_matcher.hpp"
+#include "matcher_interfaces.hpp"
 #include "sfm_data_io.hpp"
+#include "sfm_hip.h"
+
+namespace {
+
+struct Options {
+  std::string path;
+  bool cross_check = true;
+  bool progress = true;
+  int devices = 0;     // 0: every visible GPU
+  int engine = -1;     // -1: SFM_HIP_ENGINE or the library default
+};
+
+bool parse(int argc, char** argv, Options& opt) {
+  for (int i = 1; i < argc; i++) {
+    const std::string arg = argv[i];
+    if (arg == "--no-cross-check") {
+      opt.cross_check = false;
+    } else if (arg == "--quiet") {
+      opt.progress = false;
+    } else if (arg == "--devices" && i + 1 < argc) {
+      opt.devices = std::atoi(argv[++i]);
+    } else if (arg == "--engine" && i + 1 < argc) {
+      const std::string name = argv[++i];
+      if (name == "f32") opt.engine = SFM_HIP_ENGINE_F32;
+      else if (name == "f16x3") opt.engine = SFM_HIP_ENGINE_F16X3;
+      else return false;
+    } else if (!arg.empty() && arg[0] != '-' && opt.path.empty()) {
+      opt.path = arg;
+    } else {
+      return false;
+    }
+  }
+  return !opt.path.empty();
+}
+
+}  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 2 || argc > 3) return 1;
-  const bool cross = !(argc == 3 && std::strcmp(argv[2], "--no-cross-check") == 0);
-
-  SfMData sfm_data;
-  if (Load(sfm_data, argv[1])) {
-    std::printf("Load Sfm Data Finish\n");
-  } else {
-    std::printf("Load Sfm Data From %s Fails\n", argv[1]);
+  Options opt;
+  if (!parse(argc, argv, opt)) {
+    std::fprintf(stderr, "usage: %s <sfm_data.bin> [--no-cross-check] [--engine f32|f16x3] [--devices N] [--quiet]\n",
+                 argv[0]);
+    return 1;
   }
 
-  auto pair_selector = std::make_shared<ExhaustivePairBuilder>();
-  std::set<Pair> pairs;
-  pair_selector->BuildPair(sfm_data, pairs);
-  std::printf("Need To Match %lu Pairs.\n", (unsigned long)pairs.size());
+  SfMData scene;
+  const bool loaded = Load(scene, opt.path);
+  if (loaded) std::printf("Load Sfm Data Finish\n");
+  else std::printf("Load Sfm Data From %s Fails\n", opt.path.c_str());
 
+  std::set<Pair> todo;
+  ExhaustivePairBuilder().BuildPair(scene, todo);
+  std::printf("Need To Match %lu Pairs.\n", (unsigned long)todo.size());
+
+  HipBruteForceMatcher matcher(opt.devices, 0.8, opt.progress);
+  matcher.set_engine(opt.engine);
   try {
-    auto matcher = std::make_shared<HipBruteForceMatcher>();
-    matcher->Match(sfm_data, pairs, cross);
-  } catch (const std::exception& e) {
-    std::fprintf(stderr, "%s\n", e.what());
+    matcher.Match(scene, todo, opt.cross_check);
+  } catch (const std::exception& failure) {
+    std::fprintf(stderr, "%s\n", failure.what());
     return 2;
   }
-  return Save(sfm_data, argv[1]) ? 0 : 3;
+  return Save(scene, opt.path) ? 0 : 3;
 }
