@@ -197,7 +197,12 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
     jobs.push_back(PairJob{pair, &sfm_data.descriptors.at(pair.first), &sfm_data.descriptors.at(pair.second),
                            &sfm_data.key_points.at(pair.first), &sfm_data.key_points.at(pair.second),
                            &sfm_data.matches.at(pair)});
-  const int n_dev = (int)std::min<size_t>((size_t)std::min(want, visible), jobs.size());
+  // SFM_HIP_OVERSUBSCRIBE=1 lets more shards than GPUs run (shard d on GPU d modulo the number
+  // of GPUs, each with its own context and host thread): a way to exercise the multi-GPU path on
+  // a machine with fewer GPUs, not a way to go faster.
+  const char* over = std::getenv("SFM_HIP_OVERSUBSCRIBE");
+  const bool oversubscribe = over && std::string(over) == "1";
+  const int n_dev = (int)std::min<size_t>((size_t)(oversubscribe ? want : std::min(want, visible)), jobs.size());
 
   // static contiguous shards, sizes differ by at most one
   Progress progress;
@@ -211,7 +216,7 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
     const size_t hi = lo + base + ((size_t)d < extra ? 1 : 0);
     workers.emplace_back([&, d, lo, hi] {
       try {
-        run_device(d, jobs, lo, hi, ratio_, is_cross_valid, engine, progress);
+        run_device(d % visible, jobs, lo, hi, ratio_, is_cross_valid, engine, progress);
       } catch (...) {
         errors[(size_t)d] = std::current_exception();
       }

@@ -114,3 +114,28 @@ def test_gpu_stage_driver_many_images(tmp_path):
     for (a, b), rec in data["matches"].items():
         l, r, _ = oracle.match_pair(images[a], images[b], 0.8, True)
         assert rec["li"].tolist() == l.tolist() and rec["ri"].tolist() == r.tolist(), (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["f32", "f16x3"])
+def test_gpu_stage_driver_three_shards_on_one_gpu(tmp_path, engine):
+    """The multi-GPU path of the C++ class (static shards, one host thread and context per shard,
+    results written straight into the shared SfMData) with three shards forced onto the one GPU."""
+    exe = os.path.join(ROOT, "sfm_amd", "lib", "feature_match_main")
+    imgs = synth.make_image_set(7, 300, 0.5, seed=78)
+    images = {i + 3: im[:n] for i, (im, n) in enumerate(zip(imgs, (300, 250, 0, 129, 300, 1, 257)))}
+    kps = {i: synth.keypoints(len(d), i) for i, d in images.items()}
+    path = str(tmp_path / "sfm_data.bin")
+    write_sfm_bin(path, images, kps)
+    env = dict(os.environ, SFM_HIP_OVERSUBSCRIBE="1")
+    out = subprocess.run([exe, path, "--devices", "3", "--engine", engine], check=True, env=env,
+                         stdout=subprocess.PIPE, text=True).stdout
+    assert "Need To Match 21 Pairs." in out and out.count("\nFinish ") == 21 and "Finish 100.000000 %" in out
+    data = read_sfm_bin(path)
+    ids = sorted(images)
+    assert sorted(data["matches"]) == [(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]]
+    for (a, b), rec in data["matches"].items():
+        l, r, _ = oracle.match_pair(images[a], images[b], 0.8, True)
+        assert rec["li"].tolist() == l.tolist() and rec["ri"].tolist() == r.tolist(), (a, b)
+        # observations are (feature index, image id): src/sfm_data.hpp:17-25
+        assert rec["lx"].tolist() == [float(v) for v in l] and set(rec["ry"].tolist()) <= {float(b)}
