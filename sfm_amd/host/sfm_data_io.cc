@@ -1,4 +1,4 @@
-// Reader/writer for the reference's ".bin" SfMData files without cereal.
+// Reader/writer for the reference's ".bin" SfMData files without cereal (".json": sfm_data_json.cc).
 //
 // cereal's binary archive writes, for the containers used in src/sfm_data_io.cc:40-47:
 //   arithmetic value      raw bytes, native endianness
@@ -18,6 +18,11 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+
+namespace sfm_data_json {     // sfm_data_json.cc
+bool Save(const SfMData& d, const std::string& path);
+bool Load(SfMData& d, const std::string& path);
+}  // namespace sfm_data_json
 
 namespace {
 
@@ -54,10 +59,7 @@ struct Reader {
 
 bool Save(const SfMData& d, const std::string path) {
   const std::string ext = extension_of(path);
-  if (ext == "json") {
-    std::printf("Path %s: the JSON archive is not implemented in this build.\n", path.c_str());
-    return false;
-  }
+  if (ext == "json") return sfm_data_json::Save(d, path);     // sfm_data_io.cc:73-74
   if (ext != "bin") return false;
   std::ofstream os(path, std::ios::trunc | std::ios::binary);
   if (!os.is_open()) {
@@ -108,10 +110,7 @@ bool Save(const SfMData& d, const std::string path) {
 
 bool Load(SfMData& d, const std::string path) {
   const std::string ext = extension_of(path);
-  if (ext == "json") {
-    std::printf("Path %s: the JSON archive is not implemented in this build.\n", path.c_str());
-    return false;
-  }
+  if (ext == "json") return sfm_data_json::Load(d, path);     // sfm_data_io.cc:101-102
   if (ext != "bin") return false;
   std::ifstream is(path, std::ios::in | std::ios::binary);
   if (!is.is_open()) {

@@ -19,6 +19,7 @@ def cpu_driver(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("host") / "cpu_driver")
     cmd = ["g++", "-O2", "-std=c++17", "-I", HOST, "-o", exe, os.path.join(ROOT, "tests", "host", "cpu_driver.cc"),
            os.path.join(HOST, "exhaustive_pair_builder.cc"), os.path.join(HOST, "sfm_data_io.cc"),
+           os.path.join(HOST, "sfm_data_json.cc"),
            "-x", "c", "-std=c11", "-ffp-contract=off", os.path.join(ROOT, "oracle", "bf_oracle.c"), "-lm", "-pthread"]
     subprocess.run(cmd, check=True)
     return exe
@@ -61,7 +62,59 @@ def test_load_rejects_unknown_extension_and_truncated_files(cpu_driver, tmp_path
     cut = str(tmp_path / "cut.bin")
     open(cut, "wb").write(open(src, "rb").read()[:5000])
     assert subprocess.run([cpu_driver, "--roundtrip", cut, str(tmp_path / "o.bin")]).returncode == 4
-    assert subprocess.run([cpu_driver, "--roundtrip", src, str(tmp_path / "o.json")]).returncode == 5
+    bad = str(tmp_path / "bad.json")
+    open(bad, "w").write('{"value0": {"Image_Width": 1, "Views": [ {"key": 1, "value": ')
+    assert subprocess.run([cpu_driver, "--roundtrip", bad, str(tmp_path / "o.bin")]).returncode == 4
+
+
+def cereal_json_document(images, kps, matches, width, height):
+    """The document cereal's JSONOutputArchive writes for the reference's serialize() functions
+    (src/sfm_data_io.cc:13-47): unnamed values are value0, value1, ...; maps are arrays of
+    key/value objects; pairs are first/second."""
+    return {"value0": {
+        "Image_Width": width, "Image_Height": height,
+        "Views": [{"key": i, "value": {"value0": "img_%d.jpg" % i}} for i in sorted(images)],
+        "KeyPoint": [{"key": i, "value": [{"x": float(x), "y": float(y)} for x, y in kps[i]]} for i in sorted(kps)],
+        "Descriptors": [{"key": i, "value": {"value0": [float(v) for v in images[i].reshape(-1)]}} for i in sorted(images)],
+        "Matches": [{"key": {"first": a, "second": b},
+                     "value": [{"value0": float(lo[k][0]), "value1": float(lo[k][1]), "value2": float(ro[k][0]),
+                                "value3": float(ro[k][1]), "value4": int(li[k]), "value5": int(ri[k])}
+                               for k in range(len(li))]}
+                    for (a, b), (lo, ro, li, ri) in sorted(matches.items())]}}
+
+
+def test_json_archive_both_ways(cpu_driver, tmp_path):
+    import json
+    A, B, _ = synth.make_pair(40, 33, 20, seed=32)
+    images = {3: A, 8: B, 11: A[:0]}
+    kps = {i: synth.keypoints(len(d), i) + 0.25 for i, d in images.items()}
+    l, r, _ = oracle.match_pair(A, B, 0.8, True)
+    matches = {(3, 8): (kps[3][l], kps[8][r], l, r), (3, 11): (kps[3][:0], kps[11][:0], l[:0], r[:0])}
+    doc = cereal_json_document(images, kps, matches, 640, 480)
+    # a cereal-style document -> our reader -> binary archive: every value survives
+    src = str(tmp_path / "from_cereal.json")
+    json.dump(doc, open(src, "w"), indent=4)
+    as_bin = str(tmp_path / "a.bin")
+    subprocess.run([cpu_driver, "--roundtrip", src, as_bin], check=True)
+    data = read_sfm_bin(as_bin)
+    assert (data["width"], data["height"]) == (640, 480)
+    assert all(np.array_equal(data["descriptors"][i].reshape(-1, 128), images[i]) for i in images)
+    assert all(np.array_equal(np.asarray(data["key_points"][i]).reshape(-1, 2), kps[i]) for i in images)
+    assert data["matches"][(3, 8)]["li"].tolist() == l.tolist() and data["matches"][(3, 8)]["ri"].tolist() == r.tolist()
+    assert data["matches"][(3, 8)]["rx"].tolist() == kps[8][r][:, 0].tolist()
+    assert len(data["matches"][(3, 11)]) == 0
+    # binary archive -> our writer: a JSON document with cereal's structure and the same numbers
+    back = str(tmp_path / "back.json")
+    subprocess.run([cpu_driver, "--roundtrip", as_bin, back], check=True)
+    got = json.load(open(back))
+    assert got == doc
+    # members in another order, and members we do not know, are tolerated
+    odd = {"extra": [1, {"a": None}], "value0": dict(reversed(list(doc["value0"].items())), Comment="x")}
+    odd_path = str(tmp_path / "odd.json")
+    json.dump(odd, open(odd_path, "w"))
+    again = str(tmp_path / "again.bin")
+    subprocess.run([cpu_driver, "--roundtrip", odd_path, again], check=True)
+    assert open(again, "rb").read() == open(as_bin, "rb").read()
 
 
 @pytest.mark.parametrize("cross", [True, False])
