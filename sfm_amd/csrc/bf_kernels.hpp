@@ -863,9 +863,15 @@ constexpr int RR_SQ_STRIDE = 132;    // words per row of squares (128 + 4: confl
 //      and checks the completeness bound;
 //   D. queries that failed the check are re-answered by an exact scan of every
 //      candidate row, by the whole workgroup.
-__global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pairs, double ratio, int engine,
-                                                unsigned long long* __restrict__ rescanned) {
-  __shared__ __attribute__((aligned(16))) float sq[128 * RR_SQ_STRIDE];
+// PP = (query, candidate) pairs per pass of step B: 128 (two passes, 68 KiB of LDS: shortest
+// latency, for launches that do not fill the chip anyway) or 64 (four passes, 34 KiB and at most
+// 128 registers: twice the workgroups per compute unit, for batches, where the step is bound by
+// how many of its memory round trips are in flight).
+template <int PP>
+__global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev* __restrict__ pairs, double ratio,
+                                                                  int engine,
+                                                                  unsigned long long* __restrict__ rescanned) {
+  __shared__ __attribute__((aligned(16))) float sq[PP * RR_SQ_STRIDE];
   __shared__ uint32_t cand[RR_QUERIES * NCAND];
   __shared__ uint32_t bnd[RR_QUERIES];
   __shared__ float res_r[RR_QUERIES * NCAND];
@@ -969,43 +975,53 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
     }
   }
   __syncthreads();
+#if defined(SFM_K2_STOP_AFTER) && SFM_K2_STOP_AFTER == 1
+  return;   // diagnostic build: time of the list merge alone
+#endif
 
   // ---- B
   {
     const int w = tid >> 6, l = tid & 63, half = l >> 5, j = l & 31;
-    // Two passes of 128 (query, candidate) pairs.  A pass's row loads are issued as early as its
-    // registers are free -- pass 1's right after pass 0's squares went to LDS -- so that they
-    // travel while the serial sums of the previous pass run.
-    f32x4 uq[16], vc[16];
-    uint32_t cis[16];
+    // 256 / PP passes of PP (query, candidate) pairs.  A thread handles, for its 16 bytes of the
+    // row, IT consecutive pairs = IT / 4 queries with their four candidates, so a query row is
+    // loaded once per query.  A pass's row loads are issued as early as its registers are
+    // free -- the next pass's right after this pass's squares went to LDS -- so that they travel
+    // while the serial sums run.
+    constexpr int IT = PP / 8, NPASS = 256 / PP;
+    f32x4 uq[IT / 4], vc[IT];
+    uint32_t cis[IT];
     auto issue_loads = [&](int pass) {
+      const int p0 = pass * PP + w * (PP / 4) + half * IT;    // first pair of this thread in the pass
 #pragma unroll
-      for (int it = 0; it < 16; it++) {
-        const int pi = pass * 128 + w * 32 + it * 2 + half;
-        cis[it] = cand[pi];
+      for (int g = 0; g < IT / 4; g++) {
+        const int q = q0 + ((p0 + 4 * g) >> 2);
+        uq[g] = reinterpret_cast<const f32x4*>(qbase + (size_t)(q < nq ? q : q0) * DIM)[j];
+      }
+#pragma unroll
+      for (int it = 0; it < IT; it++) {
+        cis[it] = cand[p0 + it];
         const uint32_t cr = cis[it] != SENT ? cis[it] : 0u;   // any valid row; the result is not used
-        uq[it] = reinterpret_cast<const f32x4*>(qbase + (size_t)(q0 + (pi >> 2) < nq ? q0 + (pi >> 2) : q0) * DIM)[j];
         vc[it] = reinterpret_cast<const f32x4*>(obase + (size_t)cr * DIM)[j];
       }
     };
     issue_loads(0);
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
+    for (int pass = 0; pass < NPASS; pass++) {
 #pragma unroll
-      for (int it = 0; it < 16; it++) {
+      for (int it = 0; it < IT; it++) {
 #pragma clang fp contract(off)
-        const int pl = w * 32 + it * 2 + half;      // (query, candidate) inside this pass
-        const f32x4 u = uq[it], v = vc[it];
+        const int pl = w * (PP / 4) + half * IT + it;      // (query, candidate) inside this pass
+        const f32x4 u = uq[it >> 2], v = vc[it];
         f32x4 d;
         d.x = u.x - v.x; d.y = u.y - v.y; d.z = u.z - v.z; d.w = u.w - v.w;
         d.x = d.x * d.x; d.y = d.y * d.y; d.z = d.z * d.z; d.w = d.w * d.w;
         if (cis[it] != SENT) *reinterpret_cast<f32x4*>(sq + pl * RR_SQ_STRIDE + 4 * j) = d;
       }
-      if (pass == 0) issue_loads(1);
+      if (pass + 1 < NPASS) issue_loads(pass + 1);
       __syncthreads();
-      if (tid < 128) {
+      if (tid < PP) {
 #pragma clang fp contract(off)
-        const int pi = pass * 128 + tid;
+        const int pi = pass * PP + tid;
         float sum = __builtin_inff();
         if (cand[pi] != SENT) {
           const f32x4* s4 = reinterpret_cast<const f32x4*>(sq + tid * RR_SQ_STRIDE);
@@ -1025,6 +1041,11 @@ __global__ __launch_bounds__(256) void k_rerank(const PairDev* __restrict__ pair
     }
   }
 
+#if defined(SFM_K2_STOP_AFTER) && SFM_K2_STOP_AFTER == 2
+  // diagnostic build: list merge + exact distances (stored, so that they are not optimized away)
+  if (q0 + (tid >> 2) < nq) (dir == 0 ? P.fwd_dist : P.rev_dist)[q0 + (tid >> 2)] = res_r[tid];
+  return;
+#endif
   // ---- C
   if (tid < RR_QUERIES && q0 + tid < nq) {
     const int q = q0 + tid;

@@ -579,9 +579,13 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     }
     const int max_q = cross_check ? std::max(max_na, max_nb) : max_na;
     if (max_q > 0) {
-      hipLaunchKernelGGL(k_rerank, dim3((max_q + RR_QUERIES - 1) / RR_QUERIES, count, cross_check ? 2 : 1), dim3(256), 0,
-                         st, dp, ratio, ctx->engine == SFM_HIP_ENGINE_F16X3 ? ENGINE_F16X3 : ENGINE_F32,
-                         ctx->rescanned_dev);
+      const dim3 grid((max_q + RR_QUERIES - 1) / RR_QUERIES, count, cross_check ? 2 : 1);
+      const int eng = ctx->engine == SFM_HIP_ENGINE_F16X3 ? ENGINE_F16X3 : ENGINE_F32;
+      // enough workgroups for several per compute unit: the variant that lets four of them share one
+      if ((size_t)grid.x * grid.y * grid.z >= (size_t)4 * ctx->n_cu)
+        hipLaunchKernelGGL(k_rerank<64>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev);
+      else
+        hipLaunchKernelGGL(k_rerank<128>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev);
       HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_cross_compact, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
