@@ -52,7 +52,7 @@ constexpr int NCAND = 4;             // candidates re-ranked exactly per query
 constexpr int ROWPART_FIELDS = 2 * NCAND + 1;  // keys, column indices, bound key
 
 constexpr int LDS_STAGE_BYTES = SN * DIM * 4;                 // 64 KiB
-constexpr int LDS_COLBUF_WORDS = 4 * 4 * 3 * 32;              // per parity: wave, tile, k, lane
+constexpr int LDS_COLBUF_WORDS = 4 * 4 * 3 * 64;              // per parity: wave, tile, k, lane (both half-waves)
 constexpr int LDS_OFF_COLBUF = 2 * LDS_STAGE_BYTES;
 constexpr int LDS_TOTAL = LDS_OFF_COLBUF + 2 * LDS_COLBUF_WORDS * 4;
 constexpr int ROWBUF_STRIDE = 97;    // 96 keys per row + 1 word so that rows fall on different banks
@@ -402,8 +402,8 @@ __device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLi
 }
 
 // One column tile (32 columns) against the wave's 64 rows: 2 x 65 MFMAs, then the vector
-// epilogue for both accumulator tiles, then the column lists (over the wave's 64 rows) are
-// merged across the two half-waves and parked in LDS.
+// epilogue for both accumulator tiles, then each lane's column list (over its half-wave's 32 rows)
+// is parked in LDS.
 template <int ENGINE, int CT>
 __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
                                           f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tv, LaneLists& L0,
@@ -429,19 +429,11 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
   tile_fold<0>(acc0, tv, L0, cl0, cl1, cl2);
   tile_fold<1>(acc1, tv, L1, cl0, cl1, cl2);
 #endif
-  cl0 |= lowc;
-  cl1 |= lowc;
-  cl2 |= lowc;
-  // the other half-wave holds the other 32 rows of the same column: v_permlane32_swap, no LDS trip
-  const uint32_t p0 = other_half(cl0), p1 = other_half(cl1), p2 = other_half(cl2);
-  insert3(cl0, cl1, cl2, p0);
-  insert3(cl0, cl1, cl2, p1);
-  insert3(cl0, cl1, cl2, p2);
-  if (h == 0) {
-    cb[0] = cl0;
-    cb[32] = cl1;
-    cb[64] = cl2;
-  }
+  // every lane parks its list (over its half-wave's 32 rows of the column); the eight lists of a
+  // column -- four waves, two half-waves -- are merged once per stage
+  cb[0] = cl0 | lowc;
+  cb[64] = cl1 | lowc;
+  cb[128] = cl2 | lowc;
   // keep the epilogue where it is written: next to this tile pair, not sunk to the end of the stage
   anchor16(L0.r0); anchor16(L0.r1); anchor16(L0.r2);
   anchor16(L1.r0); anchor16(L1.r1); anchor16(L1.r2);
@@ -450,21 +442,30 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
-// Merge the four waves' lists of one column of a finished stage and store them.  cbaddr is the
-// LDS byte address of this lane's entry of wave 0, list entry 0; it is made opaque to the
-// optimizer so that the twelve reads stay "one register + immediate offset".
-__device__ __forceinline__ void stage_columns_out(uint32_t cbaddr, __amdgpu_buffer_rsrc_t dst, uint32_t voff,
+// Merge the eight lists of one column of a finished stage (four waves x two half-waves) and store
+// the result.  Lane (c, hh) of the wave takes column c of the wave's column tile and the lists of
+// waves 2hh and 2hh+1; the two halves are then merged with v_permlane32_swap.  cbaddr is the LDS
+// byte address of the first of the lane's twelve entries; it is made opaque to the optimizer so
+// that the reads stay "one register + immediate offset".
+__device__ __forceinline__ void stage_columns_out(uint32_t cbaddr, int hh, __amdgpu_buffer_rsrc_t dst, uint32_t voff,
                                                   uint32_t soff, uint32_t plane_bytes) {
   asm volatile("" : "+v"(cbaddr));
   const lds_u32* cb = (const lds_u32*)cbaddr;
-  uint32_t k0 = cb[0], k1 = cb[32], k2 = cb[64];
+  uint32_t k0 = cb[0], k1 = cb[64], k2 = cb[128];
 #pragma unroll
-  for (int wv = 1; wv < 4; wv++)
+  for (int li = 1; li < 4; li++) {       // (wave, half-wave) = (0,1), (1,0), (1,1) relative to the first
 #pragma unroll
-    for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[wv * 4 * 3 * 32 + k * 32]);
-  __builtin_amdgcn_raw_buffer_store_b32(k0, dst, voff, soff, 0);
-  __builtin_amdgcn_raw_buffer_store_b32(k1, dst, voff, soff + plane_bytes, 0);
-  __builtin_amdgcn_raw_buffer_store_b32(k2, dst, voff, soff + 2 * plane_bytes, 0);
+    for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[(li >> 1) * 4 * 3 * 64 + (li & 1) * 32 + k * 64]);
+  }
+  const uint32_t p0 = other_half(k0), p1 = other_half(k1), p2 = other_half(k2);
+  insert3(k0, k1, k2, p0);
+  insert3(k0, k1, k2, p1);
+  insert3(k0, k1, k2, p2);
+  if (hh == 0) {
+    __builtin_amdgcn_raw_buffer_store_b32(k0, dst, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(k1, dst, voff, soff + plane_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(k2, dst, voff, soff + 2 * plane_bytes, 0);
+  }
 }
 
 #ifdef SFM_K1_STAMPS
@@ -622,7 +623,8 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
       2 * plane_bytes + (uint32_t)blk.ncols * 4u, 0x00020000);
   const uint32_t colvoff = (uint32_t)((32 * w + r) * 4);
   const uint32_t colbuf_addr =
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + LDS_OFF_COLBUF + (uint32_t)((w * 3 * 32 + r) * 4);
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + LDS_OFF_COLBUF +
+      (uint32_t)((((2 * h) * 4 + w) * 3 * 64 + r) * 4);   // wave 2h, column tile w, entry 0, lane r of half-wave 0
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // stage 0 landed
@@ -646,18 +648,18 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
         nbn[ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ynsrc, (r + 32 * ct) * 4, (gg + 1) * SN * 4, 0));
     }
     // column lists of the previous stage: each wave merges and stores 32 of its 128 columns
-    if (gg >= 1 && h == 0)
-      stage_columns_out(colbuf_addr + (u ^ 1) * LDS_COLBUF_WORDS * 4, coldst, colvoff, (uint32_t)((gg - 1) * SN * 4),
+    if (gg >= 1)
+      stage_columns_out(colbuf_addr + (u ^ 1) * LDS_COLBUF_WORDS * 4, h, coldst, colvoff, (uint32_t)((gg - 1) * SN * 4),
                         plane_bytes);
     uint32_t tv = (uint32_t)(4 * gg);
     asm volatile("" : "+v"(tv));   // a VGPR, so that the row key is one v_and_or_b32
-    uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 3) * 32 + r;
+    uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 3) * 64 + l;
     f32x4 b[3];
     const uint32_t (&X)[8] = u == 0 ? X0 : X1;
-    tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 96, feed, yvoff);
-    tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 96, feed, yvoff);
-    tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 96, feed, yvoff);
-    tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 96, feed, yvoff);
+    tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 192, feed, yvoff);
+    tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 192, feed, yvoff);
+    tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 192, feed, yvoff);
+    tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 192, feed, yvoff);
     // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
     // compiler does not always drain it for __syncthreads(), so wait explicitly.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -669,9 +671,8 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     stage_body(std::integral_constant<int, 0>{}, g);
     stage_body(std::integral_constant<int, 1>{}, g + 1);
   }
-  if (h == 0)
-    stage_columns_out(colbuf_addr + ((nstages - 1) & 1) * LDS_COLBUF_WORDS * 4, coldst, colvoff,
-                      (uint32_t)((nstages - 1) * SN * 4), plane_bytes);
+  stage_columns_out(colbuf_addr + ((nstages - 1) & 1) * LDS_COLBUF_WORDS * 4, h, coldst, colvoff,
+                    (uint32_t)((nstages - 1) * SN * 4), plane_bytes);
 
 #ifdef SFM_K1_STAMPS
   if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
