@@ -97,3 +97,55 @@ def test_exhaustive_pairs_order():
     p = oracle.exhaustive_pairs([7, 3, 5, 11])
     assert p.tolist() == [[3, 5], [3, 7], [3, 11], [5, 7], [5, 11], [7, 11]]
     assert len(oracle.exhaustive_pairs(range(100))) == 4950
+
+
+def _numpy_model(A, B, ratio, cross):
+    """A second, independent restatement of brute_force_matcher.cc:13-41,62-86 and metric.hpp:15-22
+    (numpy float32 arithmetic, Python control flow), to catch a misreading shared by nobody."""
+    def direction(X, Y):
+        out = []
+        if len(Y) == 0:
+            return out
+        # metric.hpp:15-22: one float accumulator, dimensions in order, every operation rounded to float
+        acc = np.zeros((len(X), len(Y)), np.float32)
+        for k in range(128):
+            d = (X[:, k][:, None] - Y[:, k][None, :]).astype(np.float32)
+            acc = (acc + (d * d).astype(np.float32)).astype(np.float32)
+        dist = np.sqrt(acc).astype(np.float32)
+        fmax = np.float32(np.finfo(np.float32).max)
+        for i in range(len(X)):
+            best, second, bi = fmax, fmax, -1
+            for j in range(len(Y)):                       # :22-33, strict comparisons
+                v = dist[i, j]
+                if v < best:
+                    second, best, bi = best, v, j
+                elif v < second:
+                    second = v
+            if float(best) < ratio * float(second):      # :35, in double
+                out.append((i, bi, best))
+        return out
+    fwd = direction(A, B)
+    if not cross:
+        return fwd
+    rev = {i: j for i, j, _ in direction(B, A)}           # :69-72
+    kept = []
+    for i, j, d in fwd:
+        if j not in rev:
+            rev[j] = 0                                    # :75-78: map_[j] default-inserts 0
+        if rev[j] == i:
+            kept.append((i, j, d))
+    return kept
+
+
+@pytest.mark.parametrize("na,nb,planted,seed", [(1, 1, 1, 1), (7, 1, 0, 2), (23, 40, 12, 3), (40, 23, 12, 4), (64, 64, 40, 5)])
+@pytest.mark.parametrize("cross", [True, False])
+def test_oracle_equals_an_independent_numpy_model(na, nb, planted, seed, cross):
+    A, B, _ = synth.make_pair(na, nb, planted, seed=seed)
+    if seed == 5:                      # exact duplicates and ties as well
+        B[3] = B[9]
+        A[0] = B[3]
+        A[11] = A[12]
+    l, r, d = oracle.match_pair(A, B, 0.8, cross)
+    exp = _numpy_model(A, B, 0.8, cross)
+    assert l.tolist() == [e[0] for e in exp] and r.tolist() == [e[1] for e in exp]
+    assert d.view(np.uint32).tolist() == [int(np.float32(e[2]).view(np.uint32)) for e in exp]
