@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "bf_kernels.hpp"
@@ -156,6 +157,42 @@ void plan_chunks(PairPlan& pl, int row_blocks_in_batch_estimate, int target_bloc
   pl.rowpart_words = (size_t)pl.nchunks * ROWPART_FIELDS * pl.X->n_pad;
   pl.colpart_words = (size_t)(pl.X->n_pad / BM) * 3 * nb_pad;
   pl.best_words = 2 * (size_t)pl.X->n_pad + 2 * (size_t)nb_pad;
+}
+
+constexpr int N_XCD = 8;
+
+// Order of a pair's nrb x nch blocks (row block, chunk) for a launch whose first block of this pair
+// sits at a position congruent to first_pos modulo 8.  The grid is cut gr x gc = 8 ways, choosing the
+// cut that needs the fewest bytes of rows plus columns per rectangle; position p then takes the next
+// block of rectangle (first_pos + p) % 8, or of the next rectangle that still has blocks.
+void xcd_order(int nrb, int nch, int chunk_cols, int first_pos, std::vector<std::pair<int, int>>& out) {
+  out.clear();
+  int best_gr = 1;
+  long best_cost = -1;
+  for (int gr = 1; gr <= N_XCD; gr *= 2) {
+    const int gc = N_XCD / gr;
+    const long cost = (long)((nrb + gr - 1) / gr) * BM + (long)((nch + gc - 1) / gc) * chunk_cols;
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best_gr = gr;
+    }
+  }
+  const int gr = best_gr, gc = N_XCD / gr;
+  std::vector<std::pair<int, int>> region[N_XCD];
+  for (int i = 0; i < gr; i++)
+    for (int j = 0; j < gc; j++) {
+      const int r0 = (int)((long)nrb * i / gr), r1 = (int)((long)nrb * (i + 1) / gr);
+      const int c0 = (int)((long)nch * j / gc), c1 = (int)((long)nch * (j + 1) / gc);
+      for (int c = c0; c < c1; c++)
+        for (int rb = r0; rb < r1; rb++) region[i * gc + j].emplace_back(rb, c);
+    }
+  size_t cursor[N_XCD] = {0};
+  const size_t total = (size_t)nrb * nch;
+  for (size_t p = 0; p < total; p++) {
+    int x = (int)((first_pos + p) % N_XCD);
+    for (int tries = 0; tries < N_XCD && cursor[x] >= region[x].size(); tries++) x = (x + 1) % N_XCD;
+    out.push_back(region[x][cursor[x]++]);
+  }
 }
 
 hipEvent_t get_event(sfm_hip_ctx* ctx) {
@@ -479,6 +516,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     uint32_t* bp = (uint32_t*)L.best.p;
     size_t nb_i = 0;
     double flop = 0.0;
+    std::vector<std::pair<int, int>> order;
     for (int k = 0; k < count; k++) {
       const PairPlan& pl = plans[done + k];
       PairDev& d = hp[k];
@@ -508,21 +546,24 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       d.xscale = pl.X->scale;
       d.yscale = pl.Y->scale;
       if (pl.X->n > 0 && pl.Y->n > 0) {
-        // chunk-major: workgroups that run together stream the same columns
-        for (int c = 0; c < pl.nchunks; c++) {
+        // Workgroup i of a launch runs on XCD i % 8, each XCD with its own L2.  The pair's grid of
+        // (row block, chunk) blocks is cut into eight rectangles, one per XCD, and the blocks are
+        // laid out so that position p of the launch holds a block of rectangle p % 8: an XCD then
+        // pulls only its rectangle's rows and columns through its L2 instead of nearly everything.
+        const int nrb = pl.X->n_pad / BM, nch = pl.nchunks;
+        xcd_order(nrb, nch, pl.chunk_cols, (int)(nb_i % N_XCD), order);
+        for (const std::pair<int, int>& rc : order) {
+          const int rb = rc.first, c = rc.second;
           const int col0 = c * pl.chunk_cols;
-          const int ncols = std::min(pl.chunk_cols, pl.Y->n_pad - col0);
-          for (int rb = 0; rb < pl.X->n_pad / BM; rb++) {
-            BlockDev& b = hb[nb_i++];
-            b.pair = k;
-            b.row0 = rb * BM;
-            b.col0 = col0;
-            b.ncols = ncols;
-            b.chunk = c;
-            b.xrows = ctx->engine == SFM_HIP_ENGINE_F16X3
-                          ? (const void*)(pl.X->split + (size_t)rb * BM * 256)
-                          : (const void*)(pl.X->d + (size_t)rb * BM * DIM);
-          }
+          BlockDev& b = hb[nb_i++];
+          b.pair = k;
+          b.row0 = rb * BM;
+          b.col0 = col0;
+          b.ncols = std::min(pl.chunk_cols, pl.Y->n_pad - col0);
+          b.chunk = c;
+          b.xrows = ctx->engine == SFM_HIP_ENGINE_F16X3
+                        ? (const void*)(pl.X->split + (size_t)rb * BM * 256)
+                        : (const void*)(pl.X->d + (size_t)rb * BM * DIM);
         }
         flop += 2.0 * pl.X->n * (double)pl.Y->n * DIM;
       }
