@@ -440,6 +440,98 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---------------------------------------------------------------------------
+// ENGINE_F16X3 only: software pipeline over the column tiles of a stage.  Beside
+// v_mfma_f32_32x32x16_f16 -- unlike beside the fp32 matrix instructions -- vector instructions
+// execute concurrently, at half their usual rate (tools/mfma_valu.hip, tools/split_step_bench.hip).
+// So while the matrix instructions of column tile CT run into one pair of accumulators, the
+// finished pair of column tile CT-1 is folded into the lists: two accumulator elements per
+// even step (four matrix instructions), one per odd step (two), the remaining eight afterwards.
+// ---------------------------------------------------------------------------
+struct FoldState {
+  uint32_t cl0, cl1, cl2;   // the column list being built for the tile that is folded
+};
+
+// Element E of a finished tile pair: E < 16 is register E of the first row tile's accumulator.
+template <int E>
+__device__ __forceinline__ void fold_elem(const f32x16& p0, const f32x16& p1, uint32_t tv, LaneLists& L0, LaneLists& L1,
+                                          FoldState& f) {
+  constexpr int RT = E >> 4, REG = E & 15;
+  const uint32_t gb = __float_as_uint(RT == 0 ? p0[REG] : p1[REG]);
+  LaneLists& L = RT == 0 ? L0 : L1;
+  insert3(L.r0[REG], L.r1[REG], L.r2[REG], (gb & ROW_MASK) | tv);
+  insert3(f.cl0, f.cl1, f.cl2, (gb & COL_MASK) | (uint32_t)(RT * 32 + REG));
+}
+template <int... E>
+__device__ __forceinline__ void fold_elems(std::integer_sequence<int, E...>, const f32x16& p0, const f32x16& p1,
+                                           uint32_t tv, LaneLists& L0, LaneLists& L1, FoldState& f) {
+  (fold_elem<E>(p0, p1, tv, L0, L1, f), ...);
+}
+
+template <int CT, int S, bool FOLD, bool HAS_NEXT, int PIECE>
+__device__ __forceinline__ void pipe_step(f32x16& acc0, f32x16& acc1, const f32x4 (&a0)[16], const f32x4 (&a1)[16],
+                                          f32x4 (&b)[3], const uint32_t (&X)[8], const StageFeed& feed,
+                                          const uint32_t (&yvoff)[8], const f32x16& p0, const f32x16& p1, uint32_t tvp,
+                                          LaneLists& L0, LaneLists& L1, FoldState& f) {
+  constexpr int TOFF = CT * 32 * DIM * 4;
+  if constexpr (S + 2 < 16) {
+    lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(16 * CT + S + 2) % 3], X[(S + 2) & 7]);
+    lds_wait<2>();
+  } else if constexpr (HAS_NEXT) {
+    lds_read16<TOFF + 32 * DIM * 4>(b[(16 * CT + S + 2) % 3], X[S + 2 - 16]);
+    lds_wait<2>();
+  } else {
+    lds_wait<15 - S>();
+  }
+  const f16x8 frag = __builtin_bit_cast(f16x8, b[(16 * CT + S) % 3]);
+  if constexpr ((S & 1) == 0) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S]), frag, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S]), frag, acc1, 0, 0, 0);
+    if constexpr (FOLD) fold_elem<3 * (S / 2)>(p0, p1, tvp, L0, L1, f);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S + 1]), frag, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S + 1]), frag, acc1, 0, 0, 0);
+    if constexpr (FOLD) fold_elem<3 * (S / 2) + 1>(p0, p1, tvp, L0, L1, f);
+  } else {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S - 1]), frag, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S - 1]), frag, acc1, 0, 0, 0);
+    if constexpr (FOLD) fold_elem<3 * (S / 2) + 2>(p0, p1, tvp, L0, L1, f);
+  }
+#ifndef SFM_ABLATE_GLDS
+  if constexpr (PIECE >= 0) stage_load_piece<PIECE>(feed.src, feed.ldsbuf, feed.w, yvoff, feed.sbase);
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Column tile CT of a stage into (acc0, acc1), folding the finished pair (p0, p1) of column tile
+// CT - 1 meanwhile and parking its column lists at cbp.
+template <int CT, bool FOLD, int... S>
+__device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x16& acc0, f32x16& acc1,
+                                          const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
+                                          f32x4 (&b)[3], const uint32_t (&X)[8], const StageFeed& feed,
+                                          const uint32_t (&yvoff)[8], const f32x16& p0, const f32x16& p1, uint32_t tvp,
+                                          LaneLists& L0, LaneLists& L1, uint32_t lowc, uint32_t* cbp) {
+  if constexpr (CT == 0) {
+    lds_read16<0>(b[0], X[0]);
+    lds_read16<0>(b[1], X[1]);
+  }
+  f32x16 zero;
+#pragma unroll
+  for (int i = 0; i < 16; i++) zero[i] = 0.0f;
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
+  FoldState f{SENT, SENT, SENT};
+  (pipe_step<CT, S, FOLD, (CT < 3), (S % 4 == 1 ? 4 * CT + S / 4 : -1)>(acc0, acc1, a0, a1, b, X, feed, yvoff, p0, p1, tvp,
+                                                                        L0, L1, f),
+   ...);
+  if constexpr (FOLD) {
+    // the eight elements that found no room above, then the tile's column lists are complete
+    fold_elems(std::integer_sequence<int, 24, 25, 26, 27, 28, 29, 30, 31>{}, p0, p1, tvp, L0, L1, f);
+    cbp[0] = f.cl0 | lowc;
+    cbp[64] = f.cl1 | lowc;
+    cbp[128] = f.cl2 | lowc;
+  }
+}
+
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // Merge the eight lists of one column of a finished stage (four waves x two half-waves) and store
@@ -656,10 +748,27 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 3) * 64 + l;
     f32x4 b[3];
     const uint32_t (&X)[8] = u == 0 ? X0 : X1;
-    tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 192, feed, yvoff);
-    tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 192, feed, yvoff);
-    tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 192, feed, yvoff);
-    tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 192, feed, yvoff);
+    if constexpr (ENGINE == ENGINE_F32) {
+      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 192, feed, yvoff);
+      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 192, feed, yvoff);
+      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 192, feed, yvoff);
+      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 192, feed, yvoff);
+    } else {
+      constexpr auto STEPS = std::make_integer_sequence<int, 16>{};
+      f32x16 e0, e1, o0, o1;   // accumulators of the even and of the odd column tiles
+      pipe_tile<0, false>(STEPS, e0, e1, a0, a1, an0, an1, bn[0], b, X, feed, yvoff, o0, o1, tv, L0, L1, lowc, cb);
+      pipe_tile<1, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[1], b, X, feed, yvoff, e0, e1, tv + 0, L0, L1, lowc, cb + 0 * 192);
+      pipe_tile<2, true>(STEPS, e0, e1, a0, a1, an0, an1, bn[2], b, X, feed, yvoff, o0, o1, tv + 1, L0, L1, lowc, cb + 1 * 192);
+      pipe_tile<3, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[3], b, X, feed, yvoff, e0, e1, tv + 2, L0, L1, lowc, cb + 2 * 192);
+      // the stage's last tile has no matrix work left to hide behind
+      FoldState f{SENT, SENT, SENT};
+      fold_elems(std::make_integer_sequence<int, 32>{}, o0, o1, tv + 3, L0, L1, f);
+      cb[3 * 192 + 0] = f.cl0 | lowc;
+      cb[3 * 192 + 64] = f.cl1 | lowc;
+      cb[3 * 192 + 128] = f.cl2 | lowc;
+      anchor16(L0.r0); anchor16(L0.r1); anchor16(L0.r2);
+      anchor16(L1.r0); anchor16(L1.r1); anchor16(L1.r2);
+    }
     // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
     // compiler does not always drain it for __syncthreads(), so wait explicitly.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
