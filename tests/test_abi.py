@@ -47,3 +47,24 @@ def test_null_arguments_are_rejected_not_dereferenced():
     assert lib.sfm_hip_device_count(None) != 0
     assert lib.sfm_hip_set_engine(None, 0) != 0
     assert b"null" in lib.sfm_hip_last_error(None)
+
+
+def test_product_code_never_touches_the_oracle():
+    """The CPU oracle is test infrastructure: nothing under sfm_amd/ (Python, C++, HIP, build
+    script) may import, include, link or name it, and bench.py may use it only in its CPU-baseline leg."""
+    import os
+    from conftest import ROOT
+    offenders = []
+    for base, _, files in os.walk(os.path.join(ROOT, "sfm_amd")):
+        if "__pycache__" in base or base.endswith(os.sep + "lib"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hpp", ".h", ".cc", ".hip", ".cpp")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if "oracle" in text.lower():
+                    offenders.append(os.path.join(base, f))
+    assert offenders == []
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [i for i, line in enumerate(bench.split("\n")) if "oracle" in line and "import" in line]
+    body = bench[bench.index("def cpu_baseline"):bench.index("def replication_check")]
+    assert len(uses) == 1 and "from oracle import oracle" in body
