@@ -958,7 +958,44 @@ __device__ __forceinline__ double excluded_lower_bound_split(uint32_t boundkey, 
   return scaled / sigma;
 }
 
+// The other side of the same analysis: an upper bound on the reference's squared sum of the column
+// a key belongs to.  The key's value bits v satisfy |g| < v (1 + 2^-14) (at most 9 low mantissa
+// bits were replaced), t <= |g| (1 + u) + E with the same absolute error term E as above, and the
+// reference's sum is at most t (1 + 160u).
+__device__ __forceinline__ double key_upper_bound(uint32_t key, uint32_t mask, float nq, float nomax) {
+  const double u = 5.9604644775390625e-8;
+  const double v = (double)__uint_as_float(key & mask);
+  return v * (1.0 + 6.2e-5 + 400.0 * u) + 460.0 * u * ((double)nq + (double)nomax);
+}
+__device__ __forceinline__ double key_upper_bound_split(uint32_t key, uint32_t mask, float nq, float nomax, float sq,
+                                                        float so) {
+  const double u = 5.9604644775390625e-8;
+  const double sigma = (double)sq * (double)so;
+  const double v = (double)__uint_as_float(key & mask);
+  const double floor_term = 2.0 * 6.103515625e-5 * 11.32 *
+                            (sqrt((double)nq) * (double)sq + sqrt((double)nomax) * (double)so);
+  return (v * (1.0 + 6.2e-5 + 400.0 * u) + 1120.0 * u * sigma * ((double)nq + (double)nomax) + floor_term * 1.001) /
+         sigma;
+}
+
+// Largest float <= x and smallest float >= x (x finite, or +inf).
+__device__ __forceinline__ float float_below(double x) {
+  float f = (float)x;
+  if ((double)f > x) f = __uint_as_float(f > 0.0f ? __float_as_uint(f) - 1u : (f == 0.0f ? 0x80000001u : __float_as_uint(f) + 1u));
+  return f;
+}
+__device__ __forceinline__ float float_above(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = __uint_as_float(f > 0.0f ? __float_as_uint(f) + 1u : (f == 0.0f ? 1u : __float_as_uint(f) - 1u));
+  return f;
+}
+
 constexpr int RR_QUERIES = 64;       // queries per workgroup of k_rerank
+// How a query is answered after its lists are merged (decided from the key values alone):
+constexpr int RR_FULL = 0;     // exact distances of all four candidates, then the rule and the completeness check
+constexpr int RR_REJECT = 1;   // whatever the exact values are, the ratio test fails: nothing to compute
+constexpr int RR_ACCEPT = 2;   // the first candidate is the nearest and passes the ratio test whatever the exact
+                               // values are: only its distance is computed (it is part of the output)
 constexpr int RR_SQ_STRIDE = 132;    // words per row of squares (128 + 4: conflict-free b128 reads)
 
 // k_rerank: grid (ceil(max queries / 64), pairs, directions), 256 threads.
@@ -986,6 +1023,7 @@ __global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev*
   __shared__ uint32_t bnd[RR_QUERIES];
   __shared__ float res_r[RR_QUERIES * NCAND];
   __shared__ int unsafe_q[RR_QUERIES];
+  __shared__ int mode[RR_QUERIES];
   __shared__ int n_unsafe;
 
   const PairDev& P = pairs[blockIdx.y];
@@ -1008,6 +1046,7 @@ __global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev*
   {
     const int ql = tid >> 2, sub = tid & 3;
     const int q = q0 + ql;
+    const float qn_early = q < nq ? qn_arr[q] : 0.0f;   // for the decision at the end of this step
     Top5 t;
     top5_init(t);
     uint32_t bound = SENT;
@@ -1077,11 +1116,51 @@ __global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev*
     // The four lanes now hold the same five entries, but equal keys may sit in a different
     // order in each lane: one lane alone names the candidates.
     if (sub == 0) {
-      cand[tid + 0] = (t.v0 != SENT && (int)t.i0 < no) ? t.i0 : SENT;
-      cand[tid + 1] = (t.v1 != SENT && (int)t.i1 < no) ? t.i1 : SENT;
-      cand[tid + 2] = (t.v2 != SENT && (int)t.i2 < no) ? t.i2 : SENT;
-      cand[tid + 3] = (t.v3 != SENT && (int)t.i3 < no) ? t.i3 : SENT;
+      uint32_t c0 = (t.v0 != SENT && (int)t.i0 < no) ? t.i0 : SENT;
+      uint32_t c1 = (t.v1 != SENT && (int)t.i1 < no) ? t.i1 : SENT;
+      uint32_t c2 = (t.v2 != SENT && (int)t.i2 < no) ? t.i2 : SENT;
+      uint32_t c3 = (t.v3 != SENT && (int)t.i3 < no) ? t.i3 : SENT;
+      // Most queries are decided by the keys alone.  Every column's reference sum lies in
+      // [lower bound, upper bound] of its key; the columns outside the candidates lie above the
+      // lower bound of the bound key.  The keys are sorted, so with lo_i, hi_i the interval of
+      // candidate i and lx the excluded columns' lower bound:
+      //   the nearest is >= min(lo_0, lx) and the second nearest <= hi_1:
+      //       sqrt(min(lo_0, lx)) >= ratio * sqrt(hi_1)  =>  brute_force_matcher.cc:35 fails;
+      //   candidate 0 <= hi_0 and everything else >= min(lo_1, lx):
+      //       sqrt(hi_0) < ratio * sqrt(min(lo_1, lx))   =>  candidate 0 is the nearest and passes.
+      // Square roots are taken of floats rounded outwards (sqrtf is monotone), in double as the rule.
+      int md = RR_FULL;
+      if (q < nq && c0 != SENT && c1 != SENT && c2 != SENT && c3 != SENT && bound != SENT && ratio > 0.0 && ratio <= 1.0) {
+        const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
+        const float nqv = qn_early;
+        double lo0, lo1, hi0, hi1, lx;
+        if (engine == ENGINE_F32) {
+          lo0 = excluded_lower_bound(t.v0, mask, nqv, other_max);
+          lo1 = excluded_lower_bound(t.v1, mask, nqv, other_max);
+          lx = excluded_lower_bound(bound, mask, nqv, other_max);
+          hi0 = key_upper_bound(t.v0, mask, nqv, other_max);
+          hi1 = key_upper_bound(t.v1, mask, nqv, other_max);
+        } else {
+          const float sq = dir == 0 ? P.xscale[0] : P.yscale[0];
+          const float so = dir == 0 ? P.yscale[0] : P.xscale[0];
+          lo0 = excluded_lower_bound_split(t.v0, mask, nqv, other_max, sq, so);
+          lo1 = excluded_lower_bound_split(t.v1, mask, nqv, other_max, sq, so);
+          lx = excluded_lower_bound_split(bound, mask, nqv, other_max, sq, so);
+          hi0 = key_upper_bound_split(t.v0, mask, nqv, other_max, sq, so);
+          hi1 = key_upper_bound_split(t.v1, mask, nqv, other_max, sq, so);
+        }
+        const double near_lo = fmax(0.0, fmin(lo0, lx)), rest_lo = fmax(0.0, fmin(lo1, lx));
+        if ((double)sqrtf(float_below(near_lo)) >= ratio * (double)sqrtf(float_above(hi1))) md = RR_REJECT;
+        else if ((double)sqrtf(float_above(hi0)) < ratio * (double)sqrtf(float_below(rest_lo))) md = RR_ACCEPT;
+      }
+      if (md == RR_REJECT) c0 = SENT;
+      if (md != RR_FULL) c1 = c2 = c3 = SENT;
+      cand[tid + 0] = c0;
+      cand[tid + 1] = c1;
+      cand[tid + 2] = c2;
+      cand[tid + 3] = c3;
       bnd[ql] = bound;
+      mode[ql] = md;
     }
   }
   __syncthreads();
@@ -1103,16 +1182,17 @@ __global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev*
     auto issue_loads = [&](int pass) {
       const int p0 = pass * PP + w * (PP / 4) + half * IT;    // first pair of this thread in the pass
 #pragma unroll
+      for (int it = 0; it < IT; it++) cis[it] = cand[p0 + it];
+#pragma unroll
       for (int g = 0; g < IT / 4; g++) {
+        // a query decided by its keys needs no rows at all (its first candidate is the one kept, if any)
         const int q = q0 + ((p0 + 4 * g) >> 2);
-        uq[g] = reinterpret_cast<const f32x4*>(qbase + (size_t)(q < nq ? q : q0) * DIM)[j];
+        if ((cis[4 * g] & cis[4 * g + 1] & cis[4 * g + 2] & cis[4 * g + 3]) != SENT)
+          uq[g] = reinterpret_cast<const f32x4*>(qbase + (size_t)(q < nq ? q : q0) * DIM)[j];
       }
 #pragma unroll
-      for (int it = 0; it < IT; it++) {
-        cis[it] = cand[p0 + it];
-        const uint32_t cr = cis[it] != SENT ? cis[it] : 0u;   // any valid row; the result is not used
-        vc[it] = reinterpret_cast<const f32x4*>(obase + (size_t)cr * DIM)[j];
-      }
+      for (int it = 0; it < IT; it++)
+        if (cis[it] != SENT) vc[it] = reinterpret_cast<const f32x4*>(obase + (size_t)cis[it] * DIM)[j];
     };
     issue_loads(0);
 #pragma unroll 1
@@ -1157,7 +1237,14 @@ __global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev*
   return;
 #endif
   // ---- C
-  if (tid < RR_QUERIES && q0 + tid < nq) {
+  if (tid < RR_QUERIES && q0 + tid < nq && mode[tid] != RR_FULL) {
+    const int q = q0 + tid;
+    int32_t* best = dir == 0 ? P.fwd_best : P.rev_best;
+    float* dist = dir == 0 ? P.fwd_dist : P.rev_dist;
+    const bool accept = mode[tid] == RR_ACCEPT;
+    best[q] = accept ? (int32_t)cand[tid * NCAND] : -1;
+    dist[q] = accept ? sqrtf(res_r[tid * NCAND]) : 0.0f;
+  } else if (tid < RR_QUERIES && q0 + tid < nq) {
     const int q = q0 + tid;
     Top2 t;
     top2_init(t);
