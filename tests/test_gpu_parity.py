@@ -225,3 +225,28 @@ def test_ragged_batch_in_one_call(matcher):
     for (a, b), got in zip(pairs, res):
         exp = oracle.match_pair(imgs[a - 100], imgs[b - 100], 0.8, True, threads=4)
         assert_same(got, exp, "pair %s" % ((a, b),))
+
+
+@pytest.mark.parametrize("scale", [1.0, 37.0])
+def test_ratio_test_at_its_threshold(matcher, scale):
+    """Queries whose nearest / second-nearest distance ratio straddles 0.8 within a few parts per
+    million: the decision must come from the exact arithmetic, never from the approximate keys."""
+    rng = np.random.default_rng(5)
+    n = 600
+    A = synth.rootsift_rows(n, 123)
+    B = synth.rootsift_rows(2 * n + 300, 124)
+    for i in range(n):
+        e1 = rng.standard_normal(128)
+        e1 /= np.linalg.norm(e1)
+        e2 = rng.standard_normal(128)
+        e2 -= e2.dot(e1) * e1
+        e2 /= np.linalg.norm(e2)
+        delta = 0.05 + 0.1 * rng.random()
+        eps = (rng.random() - 0.5) * 2e-5                      # ratio = 0.8 * (1 + eps)
+        B[2 * i] = (A[i] + delta * 0.8 * (1 + eps) * e1).astype(np.float32)
+        B[2 * i + 1] = (A[i] + delta * e2).astype(np.float32)
+    A = (A * np.float32(scale)).astype(np.float32)
+    B = (B * np.float32(scale)).astype(np.float32)
+    l, r, d = check_pair(matcher, A, B, False)
+    assert 0.2 * n < len(l) < 0.8 * n                          # the cases really fall on both sides
+    check_pair(matcher, A, B, True)
