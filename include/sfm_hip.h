@@ -144,6 +144,97 @@ int sfm_hip_set_profiling(sfm_hip_ctx* ctx, int enabled);
 int sfm_hip_get_stats(sfm_hip_ctx* ctx, sfm_hip_stats* out);
 int sfm_hip_reset_stats(sfm_hip_ctx* ctx);
 
+/* ------------------------------------------------------------------------------------------
+ * Cascade-hash matcher: the GPU side of CascadeHashMatcher::Match
+ * (src/feature_matcher/cascade_hash_matcher.hpp:24-45, .cc:118-205), the matcher the reference's
+ * driver runs (src/feature_match_main.cc:26).  Images are the ones uploaded with
+ * sfm_hip_upload_image.  The order of calls mirrors the reference's Match():
+ *   1. sfm_hip_cascade_set_projection   the random projections (.cc:127-146)
+ *   2. sfm_hip_cascade_column_sums      each image's share of the mean (.cc:157-163); the caller
+ *                                       adds the shares in the reference's order and divides (.cc:165)
+ *   3. sfm_hip_cascade_hash_images      ConstructHashDescriptors for every image (.cc:167-170)
+ *   4. sfm_hip_cascade_match_pairs      DescriptorMath in both directions + cross-check (.cc:173-195)
+ * Sums of floats (the column sums, the 188 projections of a descriptor) are taken in index order
+ * with one fp32 accumulator and unfused multiply and add; the reference leaves that order to its
+ * matrix library.
+ * ------------------------------------------------------------------------------------------ */
+#define SFM_HIP_CASCADE_GROUPS 6        /* bucket_group_size, cascade_hash_matcher.cc:122 */
+#define SFM_HIP_CASCADE_GROUP_BITS 10   /* bits_of_group, :123 */
+#define SFM_HIP_CASCADE_CODE_BITS 128   /* hash_code_size, :124 */
+
+/* Counters of the cascade-hash path since context creation or the last reset. */
+typedef struct {
+  uint64_t pairs;           /* image pairs matched */
+  uint64_t images_hashed;   /* images passed through sfm_hip_cascade_hash_images */
+  uint64_t match_launches;  /* batches of sfm_hip_cascade_match_pairs that were timed */
+  double match_ms;          /* their summed duration on the GPU, first kernel to last (HIP events on
+                               the stream they run on; only while profiling is enabled) */
+  double match_bytes;       /* bytes those batches had to move at the least: every bucket-sorted hash
+                               record of both images once per pass that reads them, the per-query
+                               work space, the results */
+} sfm_hip_cascade_stats;
+
+/* The projection matrices of cascade_hash_matcher.cc:130-146: primary[128][128] (row i produces hash
+ * bit i) and secondary[6][10][128] (row k of group t produces bit k of that group's bucket id,
+ * first row = most significant bit, .cc:33-35), both row-major host memory.  The reference draws
+ * them from std::mt19937 and std::normal_distribution, which belong to the C++ standard library
+ * of the caller; that is why they are an input here. */
+int sfm_hip_cascade_set_projection(sfm_hip_ctx* ctx, const float* primary, const float* secondary);
+
+/* For each of n_images uploaded images the 128 sums the reference adds into its mean vector
+ * (cascade_hash_matcher.cc:158-162): the reference views the row-major n x 128 descriptor block as a
+ * column-major matrix, so entry c is the sum of the c-th run of n consecutive floats of the block.
+ * out_sums: n_images x 128 floats, host memory.  Blocking. */
+int sfm_hip_cascade_column_sums(sfm_hip_ctx* ctx, const int64_t* image_ids, int32_t n_images, float* out_sums);
+
+/* ConstructHashDescriptors (cascade_hash_matcher.cc:11-49) for n_images uploaded images with the
+ * vector mean128 subtracted from every descriptor (.cc:21): 128-bit hash codes, six 10-bit bucket
+ * ids per descriptor, and per group the descriptors sorted by bucket (ascending index inside a
+ * bucket, as .cc:43-46 fills them).  Results stay on the GPU.  Hashing an image again replaces its
+ * hashes; uploading an image again discards them.  Blocking. */
+int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int32_t n_images, const float* mean128);
+
+/* Copy one image's hashes to the host: codes n x 4 words (hash bit j is bit j % 32 of word j / 32),
+ * bucket_ids n x 6.  Either pointer may be NULL.  For tests and inspection. */
+int sfm_hip_cascade_get_hashes(sfm_hip_ctx* ctx, int64_t image_id, uint32_t* codes, uint16_t* bucket_ids);
+
+/* Match n_pairs pairs of hashed images: DescriptorMath (cascade_hash_matcher.cc:51-116) from the
+ * first image to the second and, with cross_check, back, then the filter of .cc:182-193.  For pair p
+ * the surviving matches, ascending in lhs index, are written to out_lhs_idx / out_rhs_idx /
+ * out_dist[p*out_stride + m] for m < out_counts[p], as in sfm_hip_match_pairs (out_dist: the L2
+ * distance of the match, src/metric.hpp:15-22; may be NULL).  out_defaults[p] receives the number of
+ * value-initialised records {lhs_idx 0, rhs_idx 0} the reference stores IN FRONT of those matches:
+ * with cross_check it builds the result in `Matches temp(matches.size())` (.cc:187), a vector that
+ * already holds one default record per forward match, and appends to it; without cross_check the
+ * number is 0.  Asynchronous like sfm_hip_match_pairs; outputs are valid after sfm_hip_sync(). */
+int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pairs, int cross_check,
+                                int32_t* out_defaults, int32_t* out_counts, int32_t* out_lhs_idx,
+                                int32_t* out_rhs_idx, float* out_dist, int64_t out_stride);
+
+/* Host-only helpers that reproduce what the reference leaves to the C++ standard library, for
+ * callers that are not written in C++ (a C++ caller can equally use <random> and
+ * <unordered_set> itself, as sfm_amd/host/hip_cascade_hash_matcher.cc does):
+ *   reference_projection  the matrices of cascade_hash_matcher.cc:127-146 -- std::mt19937 with its
+ *                         default seed feeding one std::normal_distribution<> (mean 0, deviation 1),
+ *                         128 x 128 draws for primary, then 6 x 10 x 128 for secondary;
+ *   image_order           the image ids of a pair list (2*n_pairs values, in the order of the
+ *                         std::set the reference walks) in the order in which the reference's
+ *                         std::unordered_set hands them out (.cc:148-152, :157); out_ids needs room
+ *                         for 2*n_pairs values, *out_n receives how many were written.
+ * Both use the standard library this shared library was built with. */
+int sfm_hip_cascade_reference_projection(float* primary, float* secondary);
+int sfm_hip_cascade_image_order(const int64_t* pair_ids, int32_t n_pairs, int64_t* out_ids, int32_t* out_n);
+
+/* Everything CascadeHashMatcher::Match does before its pair loop (cascade_hash_matcher.cc:122-171)
+ * for the uploaded images a pair list names: reference projection, column sums of every image,
+ * the mean vector (shares added in image_order, divided by the total descriptor count) and the
+ * hashes of every image.  out_mean128 (128 floats, may be NULL) receives the mean.  Blocking. */
+int sfm_hip_cascade_prepare(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pairs, float* out_mean128);
+
+/* Statistics of the cascade path; timing as sfm_hip_set_profiling describes. */
+int sfm_hip_cascade_get_stats(sfm_hip_ctx* ctx, sfm_hip_cascade_stats* out);
+int sfm_hip_cascade_reset_stats(sfm_hip_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

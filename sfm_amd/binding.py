@@ -16,7 +16,13 @@ EXPORTS = (
     "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
     "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats", "sfm_hip_set_engine",
     "sfm_hip_upload_image_device",
+    "sfm_hip_cascade_set_projection", "sfm_hip_cascade_column_sums", "sfm_hip_cascade_hash_images",
+    "sfm_hip_cascade_get_hashes", "sfm_hip_cascade_match_pairs", "sfm_hip_cascade_reference_projection",
+    "sfm_hip_cascade_image_order", "sfm_hip_cascade_prepare", "sfm_hip_cascade_get_stats",
+    "sfm_hip_cascade_reset_stats",
 )
+
+CASCADE_GROUPS, CASCADE_GROUP_BITS, CASCADE_CODE_BITS = 6, 10, 128
 
 
 class SfmHipError(RuntimeError):
@@ -27,6 +33,11 @@ class Stats(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_uint64), ("queries", ctypes.c_uint64), ("rescanned_queries", ctypes.c_uint64),
                 ("distance_launches", ctypes.c_uint64), ("distance_ms", ctypes.c_double),
                 ("distance_flop", ctypes.c_double)]
+
+
+class CascadeStats(ctypes.Structure):
+    _fields_ = [("pairs", ctypes.c_uint64), ("images_hashed", ctypes.c_uint64), ("match_launches", ctypes.c_uint64),
+                ("match_ms", ctypes.c_double), ("match_bytes", ctypes.c_double)]
 
 
 def library_path():
@@ -72,8 +83,45 @@ def library():
     lib.sfm_hip_set_engine.argtypes = [vp, ctypes.c_int]
     lib.sfm_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     lib.sfm_hip_reset_stats.argtypes = [vp]
+    lib.sfm_hip_cascade_set_projection.argtypes = [vp, vp, vp]
+    lib.sfm_hip_cascade_column_sums.argtypes = [vp, vp, i32, vp]
+    lib.sfm_hip_cascade_hash_images.argtypes = [vp, vp, i32, vp]
+    lib.sfm_hip_cascade_get_hashes.argtypes = [vp, i64, vp, vp]
+    lib.sfm_hip_cascade_match_pairs.argtypes = [vp, vp, i32, ctypes.c_int, vp, vp, vp, vp, vp, i64]
+    lib.sfm_hip_cascade_reference_projection.argtypes = [vp, vp]
+    lib.sfm_hip_cascade_image_order.argtypes = [vp, i32, vp, ctypes.POINTER(i32)]
+    lib.sfm_hip_cascade_prepare.argtypes = [vp, vp, i32, vp]
+    lib.sfm_hip_cascade_get_stats.argtypes = [vp, ctypes.POINTER(CascadeStats)]
+    lib.sfm_hip_cascade_reset_stats.argtypes = [vp]
     _lib = lib
     return lib
+
+
+def cascade_reference_projection():
+    """(primary [128, 128], secondary [6, 10, 128]): the matrices of cascade_hash_matcher.cc:127-146."""
+    p = np.empty((CASCADE_CODE_BITS, 128), np.float32)
+    q = np.empty((CASCADE_GROUPS, CASCADE_GROUP_BITS, 128), np.float32)
+    rc = library().sfm_hip_cascade_reference_projection(p.ctypes.data, q.ctypes.data)
+    if rc != 0:
+        raise SfmHipError("sfm_hip_cascade_reference_projection failed (%d)" % rc)
+    return p, q
+
+
+def _sorted_pairs(pairs):
+    """The pair list as the reference walks it: a std::set of (first, second), ascending."""
+    p = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    return np.ascontiguousarray(sorted(set(map(tuple, p.tolist()))), dtype=np.int64).reshape(-1, 2)
+
+
+def cascade_image_order(pairs):
+    """Image ids of a pair list in the order the reference adds their shares to the mean."""
+    p = _sorted_pairs(pairs)
+    out = np.empty(max(2 * len(p), 1), np.int64)
+    n = ctypes.c_int32(0)
+    rc = library().sfm_hip_cascade_image_order(p.ctypes.data, len(p), out.ctypes.data, ctypes.byref(n))
+    if rc != 0:
+        raise SfmHipError("sfm_hip_cascade_image_order failed (%d)" % rc)
+    return out[:n.value].copy()
 
 
 class _Pinned:
@@ -115,6 +163,10 @@ class Matcher:
                 for b in self._bufs:
                     b.free()
                 self._bufs = None
+            if getattr(self, "_cbufs", None):
+                for b in self._cbufs:
+                    b.free()
+                self._cbufs = None
             self._lib.sfm_hip_ctx_destroy(self._h)
             self._h = None
 
@@ -190,6 +242,89 @@ class Matcher:
             c = int(cnt[k])
             out.append((lhs[k, :c].astype(np.int64), rhs[k, :c].astype(np.int64), dist[k, :c].copy()))
         return out
+
+    # ---- cascade-hash matcher -------------------------------------------------------------
+    def cascade_set_projection(self, primary, secondary):
+        p = np.ascontiguousarray(primary, dtype=np.float32)
+        q = np.ascontiguousarray(secondary, dtype=np.float32)
+        if p.shape != (CASCADE_CODE_BITS, 128) or q.shape != (CASCADE_GROUPS, CASCADE_GROUP_BITS, 128):
+            raise ValueError("projection matrices must be [128, 128] and [6, 10, 128]")
+        self._check(self._lib.sfm_hip_cascade_set_projection(self._h, p.ctypes.data, q.ctypes.data),
+                    "sfm_hip_cascade_set_projection")
+
+    def cascade_column_sums(self, image_ids):
+        ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+        out = np.empty((len(ids), 128), np.float32)
+        self._check(self._lib.sfm_hip_cascade_column_sums(self._h, ids.ctypes.data, len(ids), out.ctypes.data),
+                    "sfm_hip_cascade_column_sums")
+        return out
+
+    def cascade_hash_images(self, image_ids, mean128):
+        ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+        m = np.ascontiguousarray(mean128, dtype=np.float32)
+        if m.shape != (128,):
+            raise ValueError("mean must have 128 entries")
+        self._check(self._lib.sfm_hip_cascade_hash_images(self._h, ids.ctypes.data, len(ids), m.ctypes.data),
+                    "sfm_hip_cascade_hash_images")
+
+    def cascade_get_hashes(self, image_id):
+        """(codes [n, 4] uint32, bucket_ids [n, 6] uint16)"""
+        n = self.image_size(image_id)
+        codes = np.empty((n, 4), np.uint32)
+        bids = np.empty((n, CASCADE_GROUPS), np.uint16)
+        self._check(self._lib.sfm_hip_cascade_get_hashes(self._h, int(image_id), codes.ctypes.data, bids.ctypes.data),
+                    "sfm_hip_cascade_get_hashes")
+        return codes, bids
+
+    def cascade_prepare(self, pairs):
+        """Projection, mean and hashes for the images of a pair list; returns the mean."""
+        p = _sorted_pairs(pairs)
+        mean = np.empty(128, np.float32)
+        self._check(self._lib.sfm_hip_cascade_prepare(self._h, p.ctypes.data, len(p), mean.ctypes.data),
+                    "sfm_hip_cascade_prepare")
+        return mean
+
+    def cascade_match_pairs_async(self, pairs, cross_check=True, stride=None):
+        """Queue the pairs; returns pinned (defaults, counts, lhs, rhs, dist), valid after sync()."""
+        p = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+        if stride is None:
+            stride = max([self.image_size(i) for i in set(p[:, 0].tolist())] + [1])
+        shape = (p.shape[0], int(stride))
+        if getattr(self, "_cbufs_shape", None) != shape:
+            if getattr(self, "_cbufs", None):
+                self.sync()
+                for b in self._cbufs:
+                    b.free()
+            self._cbufs = [_Pinned(self._lib, s, t) for _ in range(2)
+                           for s, t in (((shape[0],), np.int32), ((shape[0],), np.int32), (shape, np.int32),
+                                        (shape, np.int32), (shape, np.float32))]
+            self._cbufs_shape = shape
+            self._cturn = 0
+        self._cturn ^= 1
+        dfl, cnt, lhs, rhs, dist = self._cbufs[5 * self._cturn:5 * self._cturn + 5]
+        self._check(self._lib.sfm_hip_cascade_match_pairs(self._h, p.ctypes.data, p.shape[0], int(bool(cross_check)),
+                                                          dfl.ptr, cnt.ptr, lhs.ptr, rhs.ptr, dist.ptr, int(stride)),
+                    "sfm_hip_cascade_match_pairs")
+        return dfl.array, cnt.array, lhs.array, rhs.array, dist.array
+
+    def cascade_match_pairs(self, pairs, cross_check=True):
+        """[(n_default, lhs_idx int64, rhs_idx int64, dist float32)] per pair: the reference stores
+        n_default records {0, 0} followed by the (lhs_idx, rhs_idx) records."""
+        dfl, cnt, lhs, rhs, dist = self.cascade_match_pairs_async(pairs, cross_check)
+        self.sync()
+        out = []
+        for k in range(cnt.shape[0]):
+            c = int(cnt[k])
+            out.append((int(dfl[k]), lhs[k, :c].astype(np.int64), rhs[k, :c].astype(np.int64), dist[k, :c].copy()))
+        return out
+
+    def cascade_stats(self):
+        s = CascadeStats()
+        self._check(self._lib.sfm_hip_cascade_get_stats(self._h, ctypes.byref(s)), "sfm_hip_cascade_get_stats")
+        return {f: getattr(s, f) for f, _ in CascadeStats._fields_}
+
+    def cascade_reset_stats(self):
+        self._check(self._lib.sfm_hip_cascade_reset_stats(self._h), "sfm_hip_cascade_reset_stats")
 
     def set_engine(self, name):
         """'f32' (fp32 matrix instructions) or 'f16x3' (split fp16 products): include/sfm_hip.h."""

@@ -39,10 +39,17 @@ def _run(cmd):
 def build_library(force=False):
     """libsfm_hip.so: HIP kernels + C ABI (include/sfm_hip.h)."""
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("sfm_hip_capi.hip", "bf_kernels.hpp")]
-    srcs.append(os.path.join(ROOT, "include", "sfm_hip.h"))
-    if force or _newer(LIB, srcs):
-        _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", LIB, srcs[0]])
+    shared = [os.path.join(CSRC, "ctx.hpp"), os.path.join(ROOT, "include", "sfm_hip.h")]
+    units = {"sfm_hip_capi.hip": ["bf_kernels.hpp"], "sfm_hip_cascade.hip": ["cascade_kernels.hpp"]}
+    objs = []
+    for unit, headers in units.items():
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(LIBDIR, unit.replace(".hip", ".o"))
+        if force or _newer(obj, [src] + [os.path.join(CSRC, h) for h in headers] + shared):
+            _run([HIPCC] + HIP_FLAGS + ["-c", "-o", obj, src])
+        objs.append(obj)
+    if force or _newer(LIB, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 

@@ -1,0 +1,175 @@
+// Host-side state behind the C ABI of include/sfm_hip.h, shared by the translation units that
+// implement it (sfm_hip_capi.hip: brute-force matcher; sfm_hip_cascade.hip: cascade-hash matcher).
+#ifndef SFM_AMD_CSRC_CTX_HPP_
+#define SFM_AMD_CSRC_CTX_HPP_
+
+#include "../../include/sfm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace sfm_host {
+
+struct Image {
+  void* block = nullptr;    // one allocation holding everything below
+  float* d = nullptr;       // [n_pad][128]
+  uint16_t* split = nullptr;  // [n_pad][256] scaled fp16 (high, low) planes: see k_split
+  float* norms = nullptr;   // [n_pad + 2]: squared norms, then the largest norm and the largest magnitude
+  float* scale = nullptr;   // {2^e, 2^-e} of the split planes
+  int32_t n = 0, n_pad = 0;
+  // cascade-hash state (sfm_hip_cascade_hash_images): one allocation holding the hash records in
+  // image order, the six copies sorted by bucket, and the bucket offsets
+  void* hash_block = nullptr;
+  void* hash_recs = nullptr;      // [n] records of 32 bytes
+  void* hash_grouped = nullptr;   // [6][n] records, group g sorted by its bucket id, then by index
+  int32_t* hash_offsets = nullptr;  // [6][1025]
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct TimedLaunch {
+  hipEvent_t start, stop;
+  double flop;
+};
+
+// A lane = one stream with its own work space.  Consecutive batches alternate between the
+// lanes, so that the next batch's distance kernel starts while the previous batch's short
+// kernels (re-rank, compaction) are still draining; nothing is shared between two batches.
+struct Lane {
+  hipStream_t stream = nullptr;
+  // grow-only device work space
+  DevBuf tables_dev, rowpart, colpart, best, out_dev;
+  DevBuf cascade_tables, cascade_slots;          // cascade-hash matcher: pair table, per-query slots
+  std::vector<char> tables_shadow;               // what tables_dev currently holds
+  // pinned staging for the per-batch tables, two slots
+  void* stage_host[2] = {nullptr, nullptr};
+  size_t stage_bytes[2] = {0, 0};
+  hipEvent_t stage_free[2] = {nullptr, nullptr};
+  int stage_slot = 0;
+  hipEvent_t last_distance_stop = nullptr;   // stop event of this lane's latest timed distance kernel
+};
+
+constexpr int N_LANES = 2;
+
+}  // namespace sfm_host
+
+struct sfm_hip_ctx {
+  int device = 0;
+  sfm_host::Lane lanes[sfm_host::N_LANES];
+  int next_lane = 0;
+  std::map<int64_t, sfm_host::Image> images;
+  std::string last_error;
+  unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
+
+  int engine = SFM_HIP_ENGINE_F32;
+  bool profiling = false;
+  std::vector<sfm_host::TimedLaunch> timed;
+  std::vector<hipEvent_t> event_pool;
+  sfm_hip_stats stats{};
+
+  hipStream_t upload_stream = nullptr;
+  int n_cu = 256;                              // compute units of the device (one distance workgroup each)
+  size_t batch_bytes_limit = (size_t)6 << 30;  // work space per batch
+  int max_pairs_per_batch = 256;
+
+  // cascade-hash matcher
+  float* cascade_projection = nullptr;   // device: [128 + 60][128] projection rows, then the 128-float mean
+  bool cascade_has_projection = false;
+  std::vector<hipEvent_t> cascade_timing;   // start/stop pairs of timed cascade match batches
+  sfm_hip_cascade_stats cascade_stats{};
+};
+
+namespace sfm_host {
+
+extern thread_local std::string g_last_error;  // failures without a context
+
+inline int fail(sfm_hip_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->last_error = msg; else g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                 \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      return sfm_host::fail(ctx, e_ == hipErrorOutOfMemory ? SFM_HIP_ERR_NOMEM : SFM_HIP_ERR_HIP, \
+                            std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    }                                                                                      \
+  } while (0)
+
+inline int sync_all(sfm_hip_ctx* ctx) {
+  for (Lane& l : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+  return SFM_HIP_OK;
+}
+
+inline int ensure(sfm_hip_ctx* ctx, Lane& L, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return SFM_HIP_OK;
+  // the old buffer may still be in use by work queued on its lane
+  HIP_TRY(ctx, hipStreamSynchronize(L.stream));
+  if (b.p) HIP_TRY(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  size_t want = bytes + bytes / 4;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    want = bytes;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+  }
+  b.bytes = want;
+  return SFM_HIP_OK;
+}
+
+inline int ensure_stage(sfm_hip_ctx* ctx, Lane& L, int slot, size_t bytes) {
+  if (L.stage_bytes[slot] >= bytes) return SFM_HIP_OK;
+  if (L.stage_host[slot]) HIP_TRY(ctx, hipHostFree(L.stage_host[slot]));
+  L.stage_host[slot] = nullptr;
+  L.stage_bytes[slot] = 0;
+  HIP_TRY(ctx, hipHostMalloc(&L.stage_host[slot], bytes * 2, hipHostMallocDefault));
+  L.stage_bytes[slot] = bytes * 2;
+  return SFM_HIP_OK;
+}
+
+inline void free_image_hashes(Image& im) {
+  if (im.hash_block) (void)hipFree(im.hash_block);
+  im.hash_block = nullptr;
+  im.hash_recs = nullptr;
+  im.hash_grouped = nullptr;
+  im.hash_offsets = nullptr;
+}
+
+inline void free_image(Image& im) {
+  free_image_hashes(im);
+  if (im.block) (void)hipFree(im.block);
+  im = Image();
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Device address through which a kernel can write a host output buffer
+// directly, or nullptr when the buffer is ordinary pageable memory.
+inline void* device_view_of_host(void* host) {
+  if (!host) return nullptr;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, host) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (a.type != hipMemoryTypeHost) return nullptr;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return d;
+}
+
+}  // namespace sfm_host
+
+#endif  // SFM_AMD_CSRC_CTX_HPP_

@@ -1,8 +1,7 @@
 // Host side of the C ABI declared in include/sfm_hip.h: context, image store,
 // work-space management, batching of pairs into launches, result copies.
-#include "../../include/sfm_hip.h"
+#include "ctx.hpp"
 
-#include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -16,124 +15,11 @@
 #include "bf_kernels.hpp"
 
 using namespace sfm;
+using namespace sfm_host;
+
+thread_local std::string sfm_host::g_last_error;
 
 namespace {
-
-thread_local std::string g_last_error;  // failures without a context
-
-struct Image {
-  void* block = nullptr;    // one allocation holding everything below
-  float* d = nullptr;       // [n_pad][128]
-  uint16_t* split = nullptr;  // [n_pad][256] scaled fp16 (high, low) planes: see k_split
-  float* norms = nullptr;   // [n_pad + 2]: squared norms, then the largest norm and the largest magnitude
-  float* scale = nullptr;   // {2^e, 2^-e} of the split planes
-  int32_t n = 0, n_pad = 0;
-};
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-};
-
-struct TimedLaunch {
-  hipEvent_t start, stop;
-  double flop;
-};
-
-}  // namespace
-
-// A lane = one stream with its own work space.  Consecutive batches alternate between the
-// lanes, so that the next batch's distance kernel starts while the previous batch's short
-// kernels (re-rank, compaction) are still draining; nothing is shared between two batches.
-struct Lane {
-  hipStream_t stream = nullptr;
-  // grow-only device work space
-  DevBuf tables_dev, rowpart, colpart, best, out_dev;
-  std::vector<char> tables_shadow;               // what tables_dev currently holds
-  // pinned staging for the per-batch tables, two slots
-  void* stage_host[2] = {nullptr, nullptr};
-  size_t stage_bytes[2] = {0, 0};
-  hipEvent_t stage_free[2] = {nullptr, nullptr};
-  int stage_slot = 0;
-  hipEvent_t last_distance_stop = nullptr;   // stop event of this lane's latest timed distance kernel
-};
-
-constexpr int N_LANES = 2;
-
-struct sfm_hip_ctx {
-  int device = 0;
-  Lane lanes[N_LANES];
-  int next_lane = 0;
-  std::map<int64_t, Image> images;
-  std::string last_error;
-  unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
-
-  int engine = SFM_HIP_ENGINE_F32;
-  bool profiling = false;
-  std::vector<TimedLaunch> timed;
-  std::vector<hipEvent_t> event_pool;
-  sfm_hip_stats stats{};
-
-  hipStream_t upload_stream = nullptr;
-  int n_cu = 256;                              // compute units of the device (one distance workgroup each)
-  size_t batch_bytes_limit = (size_t)6 << 30;  // work space per batch
-  int max_pairs_per_batch = 256;
-};
-
-namespace {
-
-int fail(sfm_hip_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->last_error = msg; else g_last_error = msg;
-  return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                                 \
-  do {                                                                                     \
-    hipError_t e_ = (expr);                                                                \
-    if (e_ != hipSuccess) {                                                                \
-      return fail(ctx, e_ == hipErrorOutOfMemory ? SFM_HIP_ERR_NOMEM : SFM_HIP_ERR_HIP,    \
-                  std::string(#expr) + ": " + hipGetErrorString(e_));                      \
-    }                                                                                      \
-  } while (0)
-
-int sync_all(sfm_hip_ctx* ctx) {
-  for (Lane& l : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
-  return SFM_HIP_OK;
-}
-
-int ensure(sfm_hip_ctx* ctx, Lane& L, DevBuf& b, size_t bytes) {
-  if (b.bytes >= bytes) return SFM_HIP_OK;
-  // the old buffer may still be in use by work queued on its lane
-  HIP_TRY(ctx, hipStreamSynchronize(L.stream));
-  if (b.p) HIP_TRY(ctx, hipFree(b.p));
-  b.p = nullptr;
-  b.bytes = 0;
-  size_t want = bytes + bytes / 4;
-  hipError_t e = hipMalloc(&b.p, want);
-  if (e != hipSuccess) {
-    want = bytes;
-    HIP_TRY(ctx, hipMalloc(&b.p, want));
-  }
-  b.bytes = want;
-  return SFM_HIP_OK;
-}
-
-int ensure_stage(sfm_hip_ctx* ctx, Lane& L, int slot, size_t bytes) {
-  if (L.stage_bytes[slot] >= bytes) return SFM_HIP_OK;
-  if (L.stage_host[slot]) HIP_TRY(ctx, hipHostFree(L.stage_host[slot]));
-  L.stage_host[slot] = nullptr;
-  L.stage_bytes[slot] = 0;
-  HIP_TRY(ctx, hipHostMalloc(&L.stage_host[slot], bytes * 2, hipHostMallocDefault));
-  L.stage_bytes[slot] = bytes * 2;
-  return SFM_HIP_OK;
-}
-
-void free_image(Image& im) {
-  if (im.block) (void)hipFree(im.block);
-  im = Image();
-}
-
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PairPlan {
   const Image* X;
@@ -221,24 +107,6 @@ int fold_timed(sfm_hip_ctx* ctx) {
   return SFM_HIP_OK;
 }
 
-// Device address through which a kernel can write a host output buffer
-// directly, or nullptr when the buffer is ordinary pageable memory.
-void* device_view_of_host(void* host) {
-  if (!host) return nullptr;
-  hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, host) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  if (a.type != hipMemoryTypeHost) return nullptr;
-  void* d = nullptr;
-  if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  return d;
-}
-
 }  // namespace
 
 extern "C" {
@@ -295,7 +163,7 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
     if (l.stream) (void)hipStreamSynchronize(l.stream);
   for (auto& kv : ctx->images) free_image(kv.second);
   for (Lane& l : ctx->lanes) {
-    for (DevBuf* b : {&l.tables_dev, &l.rowpart, &l.colpart, &l.best, &l.out_dev})
+    for (DevBuf* b : {&l.tables_dev, &l.rowpart, &l.colpart, &l.best, &l.out_dev, &l.cascade_tables, &l.cascade_slots})
       if (b->p) (void)hipFree(b->p);
     for (int s = 0; s < 2; s++) {
       if (l.stage_host[s]) (void)hipHostFree(l.stage_host[s]);
@@ -305,6 +173,8 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   }
   if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
   if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
+  if (ctx->cascade_projection) (void)hipFree(ctx->cascade_projection);
+  for (auto e : ctx->cascade_timing) (void)hipEventDestroy(e);
   for (auto& t : ctx->timed) {
     (void)hipEventDestroy(t.start);
     (void)hipEventDestroy(t.stop);

@@ -99,6 +99,28 @@ def make_image_set(n_images, n_features, shared_fraction, seed, sigma=0.01):
     return out
 
 
+def make_repetitive_set(n_images, n_features, shared_fraction, copies, seed, sigma=0.002):
+    """Like make_image_set, but every shared scene row appears `copies` times in an image, each
+    time with its own small noise (repeated structure, as the windows of a facade produce).  A
+    query then has several near neighbours that agree in nearly all hash bits, which is what the
+    cascade-hash matcher needs before it reports anything.
+    Returns a list of float32 arrays [n_features, 128].
+    """
+    pool = rootsift_rows(n_features, _stream(seed, 11))
+    k = int(round(shared_fraction * n_features / max(copies, 1)))
+    out = []
+    for img in range(n_images):
+        s = _stream(seed, 100 + img)
+        X = rootsift_rows(n_features, _stream(s, 1))
+        if k:
+            src = permutation(n_features, _stream(s, 2))[:k]
+            dst = permutation(n_features, _stream(s, 3))[:k * copies]
+            rows = np.repeat(pool[src].astype(np.float64), copies, axis=0)
+            X[dst] = (rows + noise(k * copies, _stream(s, 4), sigma)).astype(np.float32)
+        out.append(X)
+    return out
+
+
 def keypoints(n_features, image_id):
     """(x, y) = (feature index, image id): results can be checked from observations alone."""
     kp = np.empty((n_features, 2), np.float64)

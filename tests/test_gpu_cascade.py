@@ -1,0 +1,162 @@
+"""GPU parity of the cascade-hash path (include/sfm_hip.h, sfm_hip_cascade_*) against the CPU oracle
+(oracle/cascade_oracle.cc), through the C ABI.  Everything is compared bit for bit: column sums,
+mean, hash codes, bucket ids, match indices, the number of default records and distances.
+
+Parity with the reference itself is unpinned for this matcher (no Eigen here to build it, no
+fixture in the reference); the oracle's header says which parts of the reference's text it follows
+literally and which it has to fix by convention (the order of float sums inside Eigen).
+"""
+import numpy as np
+import pytest
+
+import sfm_amd
+from sfm_amd import binding, synth
+from oracle import cascade
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    m = sfm_amd.Matcher(0)
+    yield m
+    m.close()
+
+
+def _upload(m, images):
+    m.drop_all()
+    for i, d in images.items():
+        m.upload(i, d)
+
+
+def _oracle_mean(images, pairs):
+    order = cascade.image_order(pairs)
+    return cascade.mean([images[int(i)] for i in order])
+
+
+def _check_pairs(m, images, pairs, cross):
+    got = m.cascade_match_pairs(pairs, cross_check=cross)
+    mean = _oracle_mean(images, pairs)
+    total = 0
+    for (a, b), (nd, l, r, d) in zip(pairs, got):
+        end, el, er, ed = cascade.match_pair(images[a], images[b], mean, cross)
+        assert nd == end, (a, b, nd, end)
+        assert l.tolist() == el.tolist(), (a, b)
+        assert r.tolist() == er.tolist(), (a, b)
+        assert d.view(np.uint32).tolist() == ed.view(np.uint32).tolist(), (a, b)
+        total += len(l)
+    return total
+
+
+def test_projection_and_image_order_match_the_oracle():
+    p, q = binding.cascade_reference_projection()
+    op, oq = cascade.projection()
+    assert p.view(np.uint32).tolist() == op.view(np.uint32).tolist()
+    assert q.view(np.uint32).tolist() == oq.view(np.uint32).tolist()
+    pairs = [(0, 1), (0, 2), (1, 2), (5, 9), (3, 1000000007), (40, 41)]
+    assert binding.cascade_image_order(pairs).tolist() == cascade.image_order(pairs).tolist()
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 64, 129, 1000, 8192])
+def test_column_sums_bitwise(matcher, n):
+    d = synth.rootsift_rows(n, 77 + n)
+    _upload(matcher, {3: d})
+    got = matcher.cascade_column_sums([3])[0]
+    want = cascade.image_column_sums(d)
+    assert got.view(np.uint32).tolist() == want.view(np.uint32).tolist()
+
+
+@pytest.mark.parametrize("sizes", [(700, 900), (1, 64), (65, 0), (4096, 4096)])
+def test_prepare_mean_and_hashes_bitwise(matcher, sizes):
+    images = {10 + k: synth.rootsift_rows(n, 5 + 13 * k + n) for k, n in enumerate(sizes)}
+    _upload(matcher, images)
+    pairs = [(10, 11)]
+    mean = matcher.cascade_prepare(pairs)
+    want_mean = _oracle_mean(images, pairs)
+    assert mean.view(np.uint32).tolist() == want_mean.view(np.uint32).tolist()
+    for i, d in images.items():
+        codes, bids = matcher.cascade_get_hashes(i)
+        wc, wb = cascade.hash_image(d, want_mean)
+        assert codes.tolist() == wc.tolist()
+        assert bids.tolist() == wb.tolist()
+
+
+@pytest.mark.parametrize("cross", [True, False])
+@pytest.mark.parametrize("n,copies,sigma", [(2048, 2, 0.002), (3000, 3, 0.001), (1500, 2, 0.004)])
+def test_pair_matches_identical_to_oracle(matcher, n, copies, sigma, cross):
+    a, b = synth.make_repetitive_set(2, n, 0.5, copies, seed=n + copies, sigma=sigma)
+    images = {0: a, 1: b[: n - 37]}
+    _upload(matcher, images)
+    matcher.cascade_prepare([(0, 1)])
+    assert _check_pairs(matcher, images, [(0, 1)], cross) > 50
+
+
+def test_set_of_images_all_pairs(matcher):
+    imgs = synth.make_repetitive_set(5, 1200, 0.6, 2, seed=3, sigma=0.002)
+    images = {2 * k + 1: d[: 1200 - 50 * k] for k, d in enumerate(imgs)}
+    ids = sorted(images)
+    pairs = [(a, b) for x, a in enumerate(ids) for b in ids[x + 1:]]
+    _upload(matcher, images)
+    matcher.cascade_prepare(pairs)
+    for cross in (True, False):
+        assert _check_pairs(matcher, images, pairs, cross) > 100
+    # the whole job in one oracle call, as CascadeHashMatcher::Match runs it
+    whole, _, _ = cascade.match_set(images, pairs, True)
+    got = matcher.cascade_match_pairs(pairs, True)
+    for pr, (nd, l, r, _) in zip(pairs, got):
+        wnd, wl, wr = whole[pr]
+        assert (nd, l.tolist(), r.tolist()) == (wnd, wl.tolist(), wr.tolist())
+
+
+def test_ties_and_crowded_bins(matcher):
+    """Exact duplicates: equal distances are decided by the lower index (pairs are compared as
+    (distance, index)), and a Hamming bin is taken whole even when it holds far more than ten."""
+    base = synth.rootsift_rows(600, 91)
+    a = base.copy()
+    b = synth.rootsift_rows(600, 92)
+    b[100:103] = a[5]          # three exact copies of one row: distance 0 three times
+    b[200:240] = a[7]          # forty copies: bin 0 holds 40 candidates
+    b[300] = a[9]              # a single copy: one candidate only, no match (needs two)
+    a[20:23] = a[5]            # and several queries that see the same copies
+    images = {0: a, 1: b}
+    _upload(matcher, images)
+    matcher.cascade_prepare([(0, 1)])
+    for cross in (False, True):
+        _check_pairs(matcher, images, [(0, 1)], cross)
+    (nd, l, r, d), = matcher.cascade_match_pairs([(0, 1)], False)
+    got = dict(zip(l.tolist(), r.tolist()))
+    assert got[5] == 100 and got[20] == 100 and got[7] == 200 and 9 not in got
+    assert d[l.tolist().index(5)] == 0.0
+
+
+def test_all_identical_descriptors(matcher):
+    """Every descriptor in one bucket with one hash code: the largest bins there can be."""
+    row = synth.rootsift_rows(1, 5)
+    images = {0: np.repeat(row, 300, axis=0), 1: np.repeat(row, 200, axis=0)}
+    _upload(matcher, images)
+    matcher.cascade_prepare([(0, 1)])
+    for cross in (False, True):
+        assert _check_pairs(matcher, images, [(0, 1)], cross) >= 1
+
+
+def test_empty_and_single_images(matcher):
+    d = synth.make_repetitive_set(1, 500, 0.5, 2, seed=8)[0]
+    images = {0: d, 1: np.zeros((0, 128), np.float32), 2: d[:1].copy(), 3: d.copy()}
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    _upload(matcher, images)
+    matcher.cascade_prepare(pairs)
+    for cross in (False, True):
+        _check_pairs(matcher, images, pairs, cross)
+
+
+def test_errors(matcher):
+    d = synth.rootsift_rows(100, 1)
+    _upload(matcher, {0: d, 1: d})
+    with pytest.raises(binding.SfmHipError, match="not been hashed"):
+        matcher.cascade_match_pairs([(0, 1)])
+    with pytest.raises(binding.SfmHipError, match="not uploaded"):
+        matcher.cascade_column_sums([7])
+    matcher.cascade_prepare([(0, 1)])
+    matcher.upload(1, d)       # a new upload discards the image's hashes
+    with pytest.raises(binding.SfmHipError, match="not been hashed"):
+        matcher.cascade_match_pairs([(0, 1)])
