@@ -27,6 +27,8 @@ def lib():
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
         l = ctypes.CDLL(_LIB)
         vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        l.ch_set_projection.argtypes = [vp, vp]
+        l.ch_set_projection.restype = None
         l.ch_projection.argtypes = [vp, vp]
         l.ch_projection.restype = None
         l.ch_image_order.argtypes = [vp, i64, vp]
@@ -57,6 +59,17 @@ def projection():
     s = np.empty((GROUPS, GROUP_BITS, DIM), np.float32)
     lib().ch_projection(p.ctypes.data, s.ctypes.data)
     return p, s
+
+
+def set_projection(primary=None, secondary=None):
+    """Replace the reference's projections in every later oracle call (None, None: restore them)."""
+    if primary is None or secondary is None:
+        lib().ch_set_projection(None, None)
+        return
+    p = np.ascontiguousarray(primary, dtype=np.float32)
+    s = np.ascontiguousarray(secondary, dtype=np.float32)
+    assert p.shape == (CODE_BITS, DIM) and s.shape == (GROUPS, GROUP_BITS, DIM)
+    lib().ch_set_projection(p.ctypes.data, s.ctypes.data)
 
 
 def image_order(pairs):

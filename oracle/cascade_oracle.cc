@@ -130,6 +130,13 @@ HashDescriptors construct_hash_descriptors(const float* desc, int64_t n, const f
   return h;
 }
 
+// Tests may replace the reference's random projections by matrices of their own, which lets a
+// known-answer case choose hash bits and distances independently (ch_set_projection).
+Projection g_override;
+bool g_have_override = false;
+
+Projection current_projection() { return g_have_override ? g_override : make_projection(); }
+
 struct RawMatch {
   IndexT lhs_idx = 0, rhs_idx = 0;
   float dist = 0.0f;     // not part of the reference's record; kept so that tests can compare it
@@ -204,6 +211,14 @@ std::vector<RawMatch> match_pair(const HashDescriptors& lh, const float* ld, con
 
 extern "C" {
 
+// primary [128][128], secondary [6][10][128]; both NULL: back to the reference's matrices
+void ch_set_projection(const float* primary, const float* secondary) {
+  g_have_override = primary && secondary;
+  if (!g_have_override) return;
+  g_override.primary.assign(primary, primary + (size_t)kCodeBits * kDim);
+  g_override.secondary.assign(secondary, secondary + (size_t)kGroups * kGroupBits * kDim);
+}
+
 void ch_projection(float* primary, float* secondary) {
   const Projection p = make_projection();
   std::memcpy(primary, p.primary.data(), p.primary.size() * sizeof(float));
@@ -241,7 +256,7 @@ void ch_mean(const float* const* descs, const int64_t* sizes, int64_t n_images, 
 
 // codes: n x 4 words, bit j of the hash code in word j / 32 at position j % 32; bucket_ids: n x 6
 void ch_hash(const float* desc, int64_t n, const float* mean128, uint32_t* codes, uint16_t* bucket_ids) {
-  const Projection pj = make_projection();
+  const Projection pj = current_projection();
   const HashDescriptors h = construct_hash_descriptors(desc, n, mean128, pj);
   for (int64_t i = 0; i < n; i++) {
     for (int w = 0; w < 4; w++) {
@@ -258,7 +273,7 @@ void ch_hash(const float* desc, int64_t n, const float* mean128, uint32_t* codes
 // reference puts in front of them (0 without cross-check).  Outputs need room for n_first records.
 int64_t ch_match_pair(const float* first, int64_t n_first, const float* second, int64_t n_second, const float* mean128,
                       int cross_check, int64_t* n_default, int64_t* out_lhs, int64_t* out_rhs, float* out_dist) {
-  const Projection pj = make_projection();
+  const Projection pj = current_projection();
   const HashDescriptors hf = construct_hash_descriptors(first, n_first, mean128, pj);
   const HashDescriptors hs = construct_hash_descriptors(second, n_second, mean128, pj);
   const std::vector<RawMatch> m = match_pair(hf, first, hs, second, cross_check != 0, n_default);
@@ -279,7 +294,7 @@ int64_t ch_match_set(const int64_t* ids, const float* const* descs, const int64_
                      const int64_t* pair_ids, int64_t n_pairs, int cross_check, int threads, int64_t* out_counts,
                      int64_t* out_defaults, int64_t* out_lhs, int64_t* out_rhs, double* seconds_hash,
                      double* seconds_match) {
-  const Projection pj = make_projection();
+  const Projection pj = current_projection();
   std::unordered_map<IndexT, size_t> slot;
   for (int64_t k = 0; k < n_images; k++) slot[ids[k]] = (size_t)k;
   std::vector<int64_t> order((size_t)n_images);

@@ -1,6 +1,11 @@
 // The matching stage as a program, with the GPU brute-force matcher:
 //
-//   feature_match_main <sfm_data.bin> [--no-cross-check] [--engine f32|f16x3] [--devices N] [--quiet]
+//   feature_match_main <sfm_data.bin> [--matcher brute|cascade] [--no-cross-check]
+//                      [--engine f32|f16x3] [--devices N] [--quiet]
+//
+// --matcher cascade runs the GPU cascade-hash matcher, the counterpart of the matcher the
+// reference's driver is shipped with (src/feature_match_main.cc:26); the default is the GPU
+// brute-force matcher (the alternative at src/feature_match_main.cc:27).
 //
 // What it does is what src/feature_match_main.cc:7-33 does -- read the archive, pair up all views,
 // match, write the archive back in place -- and it prints the same three kinds of lines.  As in
@@ -11,7 +16,10 @@
 #include <exception>
 #include <string>
 
+#include <memory>
+
 #include "hip_brute_force_matcher.hpp"
+#include "hip_cascade_hash_matcher.hpp"
 #include "matcher_interfaces.hpp"
 #include "sfm_data_io.hpp"
 #include "sfm_hip.h"
@@ -24,6 +32,7 @@ struct Options {
   bool progress = true;
   int devices = 0;     // 0: every visible GPU
   int engine = -1;     // -1: SFM_HIP_ENGINE or the library default
+  bool cascade = false;
 };
 
 bool parse(int argc, char** argv, Options& opt) {
@@ -35,6 +44,11 @@ bool parse(int argc, char** argv, Options& opt) {
       opt.progress = false;
     } else if (arg == "--devices" && i + 1 < argc) {
       opt.devices = std::atoi(argv[++i]);
+    } else if (arg == "--matcher" && i + 1 < argc) {
+      const std::string name = argv[++i];
+      if (name == "cascade") opt.cascade = true;
+      else if (name == "brute") opt.cascade = false;
+      else return false;
     } else if (arg == "--engine" && i + 1 < argc) {
       const std::string name = argv[++i];
       if (name == "f32") opt.engine = SFM_HIP_ENGINE_F32;
@@ -54,7 +68,9 @@ bool parse(int argc, char** argv, Options& opt) {
 int main(int argc, char** argv) {
   Options opt;
   if (!parse(argc, argv, opt)) {
-    std::fprintf(stderr, "usage: %s <sfm_data.bin> [--no-cross-check] [--engine f32|f16x3] [--devices N] [--quiet]\n",
+    std::fprintf(stderr,
+                 "usage: %s <sfm_data.bin> [--matcher brute|cascade] [--no-cross-check] [--engine f32|f16x3] "
+                 "[--devices N] [--quiet]\n",
                  argv[0]);
     return 1;
   }
@@ -68,10 +84,16 @@ int main(int argc, char** argv) {
   ExhaustivePairBuilder().BuildPair(scene, todo);
   std::printf("Need To Match %lu Pairs.\n", (unsigned long)todo.size());
 
-  HipBruteForceMatcher matcher(opt.devices, 0.8, opt.progress);
-  matcher.set_engine(opt.engine);
+  std::shared_ptr<FeatureMatcherInterface> matcher;
+  if (opt.cascade) {
+    matcher = std::make_shared<HipCascadeHashMatcher>(opt.devices, opt.progress);
+  } else {
+    auto brute = std::make_shared<HipBruteForceMatcher>(opt.devices, 0.8, opt.progress);
+    brute->set_engine(opt.engine);
+    matcher = brute;
+  }
   try {
-    matcher.Match(scene, todo, opt.cross_check);
+    matcher->Match(scene, todo, opt.cross_check);
   } catch (const std::exception& failure) {
     std::fprintf(stderr, "%s\n", failure.what());
     return 2;

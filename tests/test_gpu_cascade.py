@@ -48,13 +48,26 @@ def _check_pairs(m, images, pairs, cross):
     return total
 
 
-def test_projection_and_image_order_match_the_oracle():
-    p, q = binding.cascade_reference_projection()
-    op, oq = cascade.projection()
-    assert p.view(np.uint32).tolist() == op.view(np.uint32).tolist()
-    assert q.view(np.uint32).tolist() == oq.view(np.uint32).tolist()
-    pairs = [(0, 1), (0, 2), (1, 2), (5, 9), (3, 1000000007), (40, 41)]
-    assert binding.cascade_image_order(pairs).tolist() == cascade.image_order(pairs).tolist()
+def test_known_answer_case(matcher):
+    """The hand-derived case of tests/cascade_kat.py through the C ABI: coordinate projections in
+    place of the random ones, zero mean."""
+    from cascade_kat import build, coordinate_projection
+    A, B, expected = build()
+    p, q = coordinate_projection()
+    _upload(matcher, {0: A, 1: B})
+    matcher.cascade_set_projection(p, q)
+    matcher.cascade_hash_images([0, 1], np.zeros(128, np.float32))
+    cascade.set_projection(p, q)
+    try:
+        for cross in (False, True):
+            (nd, l, r, d), = matcher.cascade_match_pairs([(0, 1)], cross)
+            assert (nd, list(zip(l.tolist(), r.tolist()))) == expected[cross]
+            _, _, _, od = cascade.match_pair(A, B, np.zeros(128, np.float32), cross)
+            assert d.view(np.uint32).tolist() == od.view(np.uint32).tolist()
+    finally:
+        cascade.set_projection(None, None)
+        rp, rq = binding.cascade_reference_projection()
+        matcher.cascade_set_projection(rp, rq)
 
 
 @pytest.mark.parametrize("n", [0, 1, 5, 64, 129, 1000, 8192])

@@ -192,3 +192,63 @@ def test_gpu_stage_driver_three_shards_on_one_gpu(tmp_path, engine):
         assert rec["li"].tolist() == l.tolist() and rec["ri"].tolist() == r.tolist(), (a, b)
         # observations are (feature index, image id): src/sfm_data.hpp:17-25
         assert rec["lx"].tolist() == [float(v) for v in l] and set(rec["ry"].tolist()) <= {float(b)}
+
+
+def _cascade_expected(images, pairs, cross):
+    from oracle import cascade
+    whole, _, _ = cascade.match_set(images, pairs, cross)
+    return whole
+
+
+def _check_cascade_records(data, images, whole):
+    assert sorted(data["matches"]) == sorted(whole)
+    total = 0
+    for (a, b), rec in data["matches"].items():
+        nd, l, r = whole[(a, b)]
+        # cascade_hash_matcher.cc:187: one value-initialised record per forward match comes first
+        assert rec["li"].tolist() == [0] * nd + l.tolist(), (a, b)
+        assert rec["ri"].tolist() == [0] * nd + r.tolist(), (a, b)
+        # key points are (feature index, image id): observations of every record, the default ones
+        # included, come from the key points its indices name (.cc:197-202)
+        assert rec["lx"].tolist() == [float(v) for v in rec["li"]] and set(rec["ly"].tolist()) <= {float(a)}
+        assert rec["rx"].tolist() == [float(v) for v in rec["ri"]] and set(rec["ry"].tolist()) <= {float(b)}
+        total += len(l)
+    return total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross", [True, False])
+def test_gpu_stage_driver_cascade_matcher(tmp_path, cross):
+    exe = os.path.join(ROOT, "sfm_amd", "lib", "feature_match_main")
+    imgs = synth.make_repetitive_set(4, 900, 0.6, 2, seed=41, sigma=0.002)
+    images = {5 * i + 2: im[:n] for i, (im, n) in enumerate(zip(imgs, (900, 700, 900, 333)))}
+    kps = {i: synth.keypoints(len(d), i) for i, d in images.items()}
+    path = str(tmp_path / "sfm_data.bin")
+    write_sfm_bin(path, images, kps)
+    out = subprocess.run([exe, path, "--matcher", "cascade"] + ([] if cross else ["--no-cross-check"]), check=True,
+                         stdout=subprocess.PIPE, text=True).stdout
+    ids = sorted(images)
+    pairs = [(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]]
+    whole = _cascade_expected(images, pairs, cross)
+    data = read_sfm_bin(path)
+    assert _check_cascade_records(data, images, whole) > 100
+    # the reference's lines: cascade_hash_matcher.cc:166, :171, :196
+    assert "mean \n" in out and "Create Descriptors Finish\n" in out
+    for (a, b) in pairs:
+        assert "Piar : [%d,%d] %d Matches.\n" % (a, b, len(data["matches"][(a, b)])) in out
+
+
+@pytest.mark.gpu
+def test_gpu_cascade_three_shards_on_one_gpu(tmp_path):
+    exe = os.path.join(ROOT, "sfm_amd", "lib", "feature_match_main")
+    imgs = synth.make_repetitive_set(6, 500, 0.6, 2, seed=42, sigma=0.002)
+    images = {i + 1: im[:n] for i, (im, n) in enumerate(zip(imgs, (500, 0, 500, 257, 1, 500)))}
+    kps = {i: synth.keypoints(max(len(d), 1), i) for i, d in images.items()}
+    path = str(tmp_path / "sfm_data.bin")
+    write_sfm_bin(path, images, kps)
+    env = dict(os.environ, SFM_HIP_OVERSUBSCRIBE="1")
+    subprocess.run([exe, path, "--matcher", "cascade", "--devices", "3", "--quiet"], check=True, env=env)
+    ids = sorted(images)
+    pairs = [(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]]
+    whole = _cascade_expected(images, pairs, True)
+    assert _check_cascade_records(read_sfm_bin(path), images, whole) > 50
