@@ -169,9 +169,14 @@ typedef struct {
   uint64_t match_launches;  /* batches of sfm_hip_cascade_match_pairs that were timed */
   double match_ms;          /* their summed duration on the GPU, first kernel to last (HIP events on
                                the stream they run on; only while profiling is enabled) */
-  double match_bytes;       /* bytes those batches had to move at the least: every bucket-sorted hash
-                               record of both images once per pass that reads them, the per-query
-                               work space, the results */
+  double match_bytes;       /* bytes those batches had to read at the least: per pair the bucket-ordered
+                               hash records of both images once (6 groups x (48 bytes per descriptor
+                               of the first image + 16 per descriptor of the second)) and one
+                               16-byte result word per descriptor */
+  uint64_t list_overflows;  /* pairs with more close candidate pairs than their list holds, matched by
+                               the slower path that needs no list */
+  uint64_t workspace_dirty_words; /* non-zero words found in the per-query work space, which every
+                               batch leaves all zeros: anything but 0 is a defect */
 } sfm_hip_cascade_stats;
 
 /* The projection matrices of cascade_hash_matcher.cc:130-146: primary[128][128] (row i produces hash

@@ -37,7 +37,8 @@ class Stats(ctypes.Structure):
 
 class CascadeStats(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_uint64), ("images_hashed", ctypes.c_uint64), ("match_launches", ctypes.c_uint64),
-                ("match_ms", ctypes.c_double), ("match_bytes", ctypes.c_double)]
+                ("match_ms", ctypes.c_double), ("match_bytes", ctypes.c_double),
+                ("list_overflows", ctypes.c_uint64), ("workspace_dirty_words", ctypes.c_uint64)]
 
 
 def library_path():

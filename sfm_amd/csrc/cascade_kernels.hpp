@@ -7,22 +7,30 @@
 //   k_ch_group    per group a copy of the hash records sorted by bucket (stable: ascending index
 //                 inside a bucket, the order .cc:43-46 fills them in) + bucket offsets
 // Per pair (DescriptorMath both ways + cross-check, .cc:51-116, :173-195):
-//   k_ch_pairs<COUNT>    walk every (first-image descriptor, second-image descriptor) that share a
-//                        bucket; for those within Hamming distance 10 count them into both
-//                        descriptors' Hamming histograms
-//   k_ch_threshold       per query: how many Hamming bins the reference would take (.cc:95-103) and
-//                        whether that gives it the two candidates it needs (.cc:105)
-//   k_ch_pairs<NEAREST>  the same walk; exact L2 distance for the candidates inside a query's bins,
-//                        minimum kept per query as (distance, index)
-//   k_ch_compact         cross-check, ordered compaction, counts
+//   k_ch_walk<COUNT>     walk every (first-image descriptor, second-image descriptor) that share a
+//                        bucket; those within Hamming distance 10 ("close pairs") are counted into
+//                        both descriptors' Hamming histograms and appended to the pair's list
+//   k_ch_nearest         per close pair of the list: how many Hamming bins the reference would take
+//                        for either descriptor (.cc:95-103), whether that gives it the two
+//                        candidates it needs (.cc:105), and if the pair is inside those bins its
+//                        exact L2 distance, folded into a running minimum of (distance, index)
+//   k_ch_compact         cross-check, ordered compaction, counts; puts the work space back to zero
+// and, only for a pair whose close pairs did not fit its list (whole images of near-identical
+// descriptors), the same result without the list:
+//   k_ch_take_all        the bins decision for every query of the pair
+//   k_ch_walk<NEAREST>   the walk again, distances computed on the way
 //
 // Why the walk is by bucket and not by query as in the reference: "i and j share a bucket of group g"
 // and the Hamming distance are symmetric, so one walk serves both directions, and with the records
 // of a group stored in bucket order both sides of it are read as contiguous runs -- the pass is a
-// stream over 6 x (na + nb) records of 32 bytes, bound by memory, instead of a gather per query.
+// stream over 6 x (na + nb) records, bound by memory, instead of a gather per query.
 // What the reference derives from visiting order (first-seen de-duplication, the order inside a
 // Hamming bin) does not reach its result: bins are taken whole and the winner is the minimum of
 // (distance, index) pairs.
+//
+// The per-query work space is all zeros between batches: every kernel that dirties a word is
+// followed by one that restores it (k_ch_compact), so a batch neither clears nor reads the slots of
+// the (vast majority of) queries that have no close pair.
 #ifndef SFM_AMD_CSRC_CASCADE_KERNELS_HPP_
 #define SFM_AMD_CSRC_CASCADE_KERNELS_HPP_
 
@@ -51,11 +59,22 @@ static_assert(sizeof(HashRec) == 32, "hash records are read as two 16-byte words
 
 __device__ __forceinline__ uint32_t bucket_of(const HashRec& r, int g) { return (r.bids[g >> 1] >> ((g & 1) * 16)) & 0xFFFFu; }
 
-// Per-query work space of one pair and direction: 16 words.
+// Bucket-ordered copy of a record, second half: the bucket ids and the index.
+struct alignas(16) HashMeta {
+  uint32_t bids[3];
+  uint32_t idx;
+};
+
+// Per-query work space of one pair and direction: 16 words, all zero between batches.
 constexpr int SLOT_WORDS = 16;
-constexpr int SLOT_HIST = 0;       // [0 .. 10] candidates at Hamming distance h
-constexpr int SLOT_TAKE = 11;      // largest Hamming distance the reference takes for this query, -1: no match
-constexpr int SLOT_BEST = 12;      // [12, 13] 64-bit minimum of (distance bits << 32 | index)
+constexpr int SLOT_HIST = 0;       // [0 .. 10] close candidates at Hamming distance h
+constexpr int SLOT_STATE = 12;     // 0: no close candidate seen; 1: seen, but no match; 2 + h: match, bins 0..h taken
+constexpr int SLOT_BEST = 14;      // [14, 15] 64-bit maximum of ~(distance bits << 32 | index): the minimum, inverted
+constexpr uint32_t STATE_NONE = 1;
+constexpr uint32_t STATE_MATCH = 2;
+
+constexpr int LIST_H_SHIFT = 28;   // list entries: {i, j | h << 28}
+constexpr int MAX_IMAGE_ROWS = 1 << LIST_H_SHIFT;
 
 struct ImageRef {
   const float* d;
@@ -66,24 +85,28 @@ struct ImageRef {
 struct HashJob {
   const float* d;        // [n][128]
   HashRec* recs;         // [n]
-  HashRec* grouped;      // [6][n]
+  uint4* gcodes;         // [6][n] hash codes in group g's bucket order
+  HashMeta* gmeta;       // [6][n] bucket ids and index, same order
   int32_t* offsets;      // [6][1025]
   int32_t n;
   int32_t first_block;   // k_ch_hash: the job's first workgroup in the launch
 };
 
 struct CascadePair {
-  const HashRec* ga;     // first image: records grouped by bucket, [6][na]
-  const HashRec* gb;
-  const int32_t* offa;   // [6][1025]
-  const int32_t* offb;
+  const uint4* ca;       // first image: codes in bucket order, [6][na]
+  const HashMeta* ma;    //              bucket ids + index, [6][na]
+  const uint4* cb;       // second image
+  const HashMeta* mb;
+  const int32_t* offb;   // second image: bucket offsets [6][1025]
   const float* da;       // descriptor rows
   const float* db;
   uint32_t* slots_a;     // [na][16]
   uint32_t* slots_b;     // [nb][16]
+  uint2* list;           // close pairs {i, j | h << 28}
+  uint32_t* list_count;  // how many were found (may exceed list_cap: then the list is incomplete)
+  uint32_t list_cap;
   int32_t na, nb;
   int32_t out_slot;
-  int32_t pad_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -255,7 +278,8 @@ __global__ __launch_bounds__(64) void k_ch_group(const HashJob* __restrict__ job
   }
   if (lane == 63) off[BUCKETS] = n;
   __syncthreads();
-  HashRec* out = job.grouped + (size_t)g * (size_t)n;
+  uint4* out_codes = job.gcodes + (size_t)g * (size_t)n;
+  HashMeta* out_meta = job.gmeta + (size_t)g * (size_t)n;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
     const bool valid = i < n;
@@ -267,7 +291,13 @@ __global__ __launch_bounds__(64) void k_ch_group(const HashJob* __restrict__ job
     if (valid) pos = cur[b] + __popcll(same & below);
     __syncthreads();
     if (valid) {
-      out[pos] = rec;
+      out_codes[pos] = make_uint4(rec.code[0], rec.code[1], rec.code[2], rec.code[3]);
+      HashMeta m;
+      m.bids[0] = rec.bids[0];
+      m.bids[1] = rec.bids[1];
+      m.bids[2] = rec.bids[2];
+      m.idx = rec.idx;
+      out_meta[pos] = m;
       if ((same >> lane) >> 1 == 0) cur[b] = pos + 1;   // highest lane of its bucket
     }
     __syncthreads();
@@ -296,82 +326,16 @@ __device__ __forceinline__ float exact_l2(const float* __restrict__ a, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// The walk over bucket-sharing descriptor pairs.  Thread = one record of the first image in group
-// g's bucket order (so neighbouring lanes mostly sit in the same bucket and read the same run of
-// the second image's records); it loops over the second image's records of that bucket.  A pair
-// that shares buckets in several groups is handled in the lowest such group only: that is the
-// reference's "seen" map (cascade_hash_matcher.cc:84-86) without its visiting order.
-//   COUNT    Hamming histograms of both descriptors (.cc:88-91, bins above 10 are never read)
-//   NEAREST  exact distance for candidates inside the bins a query takes (.cc:95-103), running
-//            minimum of (distance, index) per query (.cc:106-111: partial_sort of pairs)
-// grid: (ceil(max na / 256), 6, pairs)
+// cascade_hash_matcher.cc:95-105 for one query, from its Hamming histogram: bins are taken whole,
+// nearest first, no new bin once ten candidates are in, none beyond distance 10; a match needs two
+// candidates.  Returns the slot state: STATE_NONE, or STATE_MATCH + the last bin taken.
 // ---------------------------------------------------------------------------------------------
-constexpr int PASS_COUNT = 0;
-constexpr int PASS_NEAREST = 1;
-
-template <int PASS>
-__global__ __launch_bounds__(256) void k_ch_pairs(const CascadePair* __restrict__ pairs, int both_directions) {
-  const CascadePair& P = pairs[blockIdx.z];
-  const int g = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int na = P.na, nb = P.nb;
-  if (p >= na) return;
-  const uint4* ga = reinterpret_cast<const uint4*>(P.ga + (size_t)g * (size_t)na + p);
-  const uint4 ca = ga[0], ma = ga[1];          // code | bids[0..2], idx
-  const uint32_t bida[3] = {ma.x, ma.y, ma.z};
-  const uint32_t ba = (bida[g >> 1] >> ((g & 1) * 16)) & 0xFFFFu;
-  const int32_t* off = P.offb + (size_t)g * (BUCKETS + 1) + ba;
-  const int s = off[0], e = off[1];
-  // which of the groups below g this record can collide in: compared as 16-bit halves
-  const uint4* gb = reinterpret_cast<const uint4*>(P.gb + (size_t)g * (size_t)nb);
-  for (int q = s; q < e; q++) {
-    const uint4 cb = gb[2 * q], mb = gb[2 * q + 1];
-    const uint32_t h = __popc(ca.x ^ cb.x) + __popc(ca.y ^ cb.y) + __popc(ca.z ^ cb.z) + __popc(ca.w ^ cb.w);
-    if (h > (uint32_t)MAX_HAMMING) continue;
-    const uint32_t x0 = ma.x ^ mb.x, x1 = ma.y ^ mb.y, x2 = ma.z ^ mb.z;
-    bool earlier = false;   // shares a bucket in a group before g
-    if (g > 0) earlier |= (x0 & 0xFFFFu) == 0;
-    if (g > 1) earlier |= (x0 >> 16) == 0;
-    if (g > 2) earlier |= (x1 & 0xFFFFu) == 0;
-    if (g > 3) earlier |= (x1 >> 16) == 0;
-    if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
-    if (earlier) continue;
-    const uint32_t i = ma.w, j = mb.w;
-    uint32_t* sa = P.slots_a + (size_t)i * SLOT_WORDS;
-    uint32_t* sb = P.slots_b + (size_t)j * SLOT_WORDS;
-    if (PASS == PASS_COUNT) {
-      atomicAdd(sa + SLOT_HIST + h, 1u);
-      if (both_directions) atomicAdd(sb + SLOT_HIST + h, 1u);
-    } else {
-      const bool fa = (int)h <= (int)sa[SLOT_TAKE];
-      const bool fb = both_directions && (int)h <= (int)sb[SLOT_TAKE];
-      if (fa || fb) {
-        // (a - b)^2 and (b - a)^2 are the same float: one distance serves both directions
-        const float dist = exact_l2(P.da + (size_t)i * DIM, P.db + (size_t)j * DIM);
-        const unsigned long long hi = (unsigned long long)__float_as_uint(dist) << 32;
-        if (fa) atomicMin(reinterpret_cast<unsigned long long*>(sa + SLOT_BEST), hi | j);
-        if (fb) atomicMin(reinterpret_cast<unsigned long long*>(sb + SLOT_BEST), hi | i);
-      }
-    }
-  }
-}
-
-// cascade_hash_matcher.cc:95-105 per query: bins are taken whole, nearest first, no new bin once ten
-// candidates are in, none beyond distance 10; a match needs two candidates.  Also resets the
-// running minimum.  One thread per query; grid: (ceil(max(na, nb) / 256), directions, pairs).
-__global__ __launch_bounds__(256) void k_ch_threshold(const CascadePair* __restrict__ pairs) {
-  const CascadePair& P = pairs[blockIdx.z];
-  const int dir = blockIdx.y;
-  const int n = dir == 0 ? P.na : P.nb;
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= n) return;
-  uint32_t* slot = (dir == 0 ? P.slots_a : P.slots_b) + (size_t)q * SLOT_WORDS;
+__device__ __forceinline__ uint32_t take_state(const uint32_t* __restrict__ slot) {
   const uint4 h0 = reinterpret_cast<const uint4*>(slot)[0];
   const uint4 h1 = reinterpret_cast<const uint4*>(slot)[1];
   const uint4 h2 = reinterpret_cast<const uint4*>(slot)[2];
   const uint32_t hist[MAX_HAMMING + 1] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z};
-  uint32_t taken = 0;
-  int last = -1;
+  uint32_t taken = 0, last = 0;
 #pragma unroll
   for (int h = 0; h <= MAX_HAMMING; h++) {
     if (taken < (uint32_t)SHORT_LIST) {
@@ -379,19 +343,184 @@ __global__ __launch_bounds__(256) void k_ch_threshold(const CascadePair* __restr
       last = h;
     }
   }
-  uint4 tail;
-  tail.x = 0xFFFFFFFFu;                       // SLOT_BEST, low word
-  tail.y = 0xFFFFFFFFu;                       // SLOT_BEST, high word
-  tail.z = 0;
-  tail.w = 0;
-  slot[SLOT_TAKE] = taken >= 2 ? (uint32_t)last : 0xFFFFFFFFu;
-  reinterpret_cast<uint4*>(slot)[3] = tail;
+  return taken >= 2 ? STATE_MATCH + last : STATE_NONE;
+}
+
+__device__ __forceinline__ bool inside_taken_bins(uint32_t state, uint32_t h) { return state >= STATE_MATCH + h; }
+
+// One close pair inside the bins of a query: its exact distance into the running minima.
+// (a - b)^2 and (b - a)^2 are the same float: one distance serves both directions.
+__device__ __forceinline__ void fold_distance(const CascadePair& P, uint32_t i, uint32_t j, bool into_a, bool into_b) {
+  const float dist = exact_l2(P.da + (size_t)i * DIM, P.db + (size_t)j * DIM);
+  const unsigned long long hi = (unsigned long long)__float_as_uint(dist) << 32;
+  if (into_a) atomicMax(reinterpret_cast<unsigned long long*>(P.slots_a + (size_t)i * SLOT_WORDS + SLOT_BEST), ~(hi | j));
+  if (into_b) atomicMax(reinterpret_cast<unsigned long long*>(P.slots_b + (size_t)j * SLOT_WORDS + SLOT_BEST), ~(hi | i));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The walk over bucket-sharing descriptor pairs.  A workgroup takes 256 consecutive records of the
+// first image in group g's bucket order; the buckets they sit in are consecutive, so the records of
+// the second image they have to meet form ONE contiguous run, which the workgroup stages in LDS
+// (codes only, 16 bytes each) and every thread then scans the part that is its own bucket.  A pair
+// that shares buckets in several groups is handled in the lowest such group only: that is the
+// reference's "seen" map (cascade_hash_matcher.cc:84-86) without its visiting order.
+//   COUNT    close pairs (Hamming distance <= 10; .cc:95 never reads further) go into both
+//            descriptors' histograms (.cc:88-91) and, through a list in LDS, into the pair's list
+//   NEAREST  only for a pair whose list overflowed: distances computed on the way (states from
+//            k_ch_take_all)
+// grid: (blocks, 6, pairs); a workgroup loops when blocks * 256 < na.
+// ---------------------------------------------------------------------------------------------
+constexpr int WALK_COUNT = 0;
+constexpr int WALK_NEAREST = 1;
+constexpr int WALK_CHUNK = 512;     // staged records per step
+constexpr int WALK_FOUND = 1024;    // close pairs a workgroup keeps in LDS before it appends them
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ch_walk(const CascadePair* __restrict__ pairs, int both_directions) {
+  __shared__ uint4 stage[WALK_CHUNK];
+  __shared__ uint2 found[MODE == WALK_COUNT ? WALK_FOUND : 1];
+  __shared__ int range[2];
+  __shared__ uint32_t n_found, list_base;
+  const CascadePair& P = pairs[blockIdx.z];
+  const int na = P.na, nb = P.nb;
+  if (MODE == WALK_NEAREST && *P.list_count <= P.list_cap) return;   // the list was complete
+  const int g = blockIdx.y;
+  const int tid = threadIdx.x;
+  const uint4* ca = P.ca + (size_t)g * (size_t)na;
+  const HashMeta* ma = P.ma + (size_t)g * (size_t)na;
+  const uint4* cb = P.cb + (size_t)g * (size_t)nb;
+  const HashMeta* mb = P.mb + (size_t)g * (size_t)nb;
+  const int32_t* off = P.offb + (size_t)g * (BUCKETS + 1);
+  for (int p0 = blockIdx.x * 256; p0 < na; p0 += gridDim.x * 256) {
+    const int p = p0 + tid;
+    const bool valid = p < na;
+    uint4 code = make_uint4(0, 0, 0, 0);
+    HashMeta meta{};
+    int s = 0, e = 0;
+    if (valid) {
+      code = ca[p];
+      meta = ma[p];
+      const uint32_t b = (meta.bids[g >> 1] >> ((g & 1) * 16)) & 0xFFFFu;
+      s = off[b];
+      e = off[b + 1];
+    }
+    if (tid == 0) {
+      range[0] = s;
+      n_found = 0;
+    }
+    if (p == min(p0 + 255, na - 1)) range[1] = e;
+    __syncthreads();
+    const int lo = range[0], hi = range[1];
+    for (int c0 = lo; c0 < hi; c0 += WALK_CHUNK) {
+      const int cnt = min(WALK_CHUNK, hi - c0);
+      for (int r = tid; r < cnt; r += 256) stage[r] = cb[c0 + r];
+      __syncthreads();
+      const int q1 = min(e, c0 + cnt);
+      for (int q = max(s, c0); q < q1; q++) {
+        const uint4 t = stage[q - c0];
+        const uint32_t h = __popc(code.x ^ t.x) + __popc(code.y ^ t.y) + __popc(code.z ^ t.z) + __popc(code.w ^ t.w);
+        if (h > (uint32_t)MAX_HAMMING) continue;
+        const HashMeta other = mb[q];
+        const uint32_t x0 = meta.bids[0] ^ other.bids[0], x1 = meta.bids[1] ^ other.bids[1], x2 = meta.bids[2] ^ other.bids[2];
+        bool earlier = false;   // shares a bucket in a group before g: counted there
+        if (g > 0) earlier |= (x0 & 0xFFFFu) == 0;
+        if (g > 1) earlier |= (x0 >> 16) == 0;
+        if (g > 2) earlier |= (x1 & 0xFFFFu) == 0;
+        if (g > 3) earlier |= (x1 >> 16) == 0;
+        if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
+        if (earlier) continue;
+        const uint32_t i = meta.idx, j = other.idx;
+        if (MODE == WALK_COUNT) {
+          atomicAdd(P.slots_a + (size_t)i * SLOT_WORDS + SLOT_HIST + h, 1u);
+          if (both_directions) atomicAdd(P.slots_b + (size_t)j * SLOT_WORDS + SLOT_HIST + h, 1u);
+          const uint2 entry = make_uint2(i, j | (h << LIST_H_SHIFT));
+          const uint32_t k = atomicAdd(&n_found, 1u);
+          if (k < (uint32_t)WALK_FOUND) {
+            found[k] = entry;
+          } else {   // more than the workgroup can hold: straight to the pair's list
+            const uint32_t at = atomicAdd(P.list_count, 1u);
+            if (at < P.list_cap) P.list[at] = entry;
+          }
+        } else {
+          const bool fa = inside_taken_bins(P.slots_a[(size_t)i * SLOT_WORDS + SLOT_STATE], h);
+          const bool fb = both_directions && inside_taken_bins(P.slots_b[(size_t)j * SLOT_WORDS + SLOT_STATE], h);
+          if (fa || fb) fold_distance(P, i, j, fa, fb);
+        }
+      }
+      __syncthreads();
+    }
+    if (MODE == WALK_COUNT) {
+      const uint32_t mine = min(n_found, (uint32_t)WALK_FOUND);
+      if (mine) {
+        if (tid == 0) list_base = atomicAdd(P.list_count, mine);
+        __syncthreads();
+        for (uint32_t k = tid; k < mine; k += 256) {
+          const uint32_t at = list_base + k;
+          if (at < P.list_cap) P.list[at] = found[k];
+        }
+      }
+    }
+    __syncthreads();   // range[], n_found and found[] are rewritten by the next round
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One thread per close pair of a pair's list: the state of both descriptors from their histograms
+// (every thread that names a descriptor stores the same value), then, if the pair lies inside the
+// bins taken for either of them, its distance.  grid: (blocks, 1, pairs), threads stride the list.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ch_nearest(const CascadePair* __restrict__ pairs, int both_directions) {
+  const CascadePair& P = pairs[blockIdx.z];
+  const uint32_t total = *P.list_count;
+  if (total > P.list_cap) return;   // incomplete list: k_ch_take_all + k_ch_walk<NEAREST> do this pair
+  for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
+    const uint2 entry = P.list[k];
+    const uint32_t i = entry.x, j = entry.y & ((1u << LIST_H_SHIFT) - 1u), h = entry.y >> LIST_H_SHIFT;
+    uint32_t* sa = P.slots_a + (size_t)i * SLOT_WORDS;
+    const uint32_t state_a = take_state(sa);
+    sa[SLOT_STATE] = state_a;
+    bool fb = false;
+    if (both_directions) {
+      uint32_t* sb = P.slots_b + (size_t)j * SLOT_WORDS;
+      const uint32_t state_b = take_state(sb);
+      sb[SLOT_STATE] = state_b;
+      fb = inside_taken_bins(state_b, h);
+    }
+    const bool fa = inside_taken_bins(state_a, h);
+    if (fa || fb) fold_distance(P, i, j, fa, fb);
+  }
+}
+
+// The bins decision for every query of a pair whose list overflowed.  One thread per query;
+// grid: (blocks, directions, pairs), threads stride the queries.
+__global__ __launch_bounds__(256) void k_ch_take_all(const CascadePair* __restrict__ pairs,
+                                                     unsigned long long* __restrict__ overflowed_pairs) {
+  const CascadePair& P = pairs[blockIdx.z];
+  if (*P.list_count <= P.list_cap) return;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(overflowed_pairs, 1ull);
+  const int n = blockIdx.y == 0 ? P.na : P.nb;
+  uint32_t* slots = blockIdx.y == 0 ? P.slots_a : P.slots_b;
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
+    uint32_t* slot = slots + (size_t)q * SLOT_WORDS;
+    const uint4 h0 = reinterpret_cast<const uint4*>(slot)[0];
+    const uint4 h1 = reinterpret_cast<const uint4*>(slot)[1];
+    const uint4 h2 = reinterpret_cast<const uint4*>(slot)[2];
+    const uint32_t any = h0.x | h0.y | h0.z | h0.w | h1.x | h1.y | h1.z | h1.w | h2.x | h2.y | h2.z;
+    if (any) slot[SLOT_STATE] = take_state(slot);
+  }
 }
 
 // Cross-check (cascade_hash_matcher.cc:182-193) and ordered compaction.  One workgroup of 1024
 // threads per pair, eight consecutive queries per thread and sweep: output order is ascending
 // lhs index.  out_defaults: the records `Matches temp(matches.size())` holds before the survivors
-// are appended (.cc:187) -- one per forward match, cross-check only.
+// are appended (.cc:187) -- one per forward match, cross-check only.  Every slot that was touched
+// goes back to zero, and so does the list counter.
+__device__ __forceinline__ void clear_slot(uint32_t* slot) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int w = 0; w < SLOT_WORDS / 4; w++) reinterpret_cast<uint4*>(slot)[w] = z;
+}
+
 __global__ __launch_bounds__(1024) void k_ch_compact(const CascadePair* __restrict__ pairs, int cross_check,
                                                      int32_t* __restrict__ out_defaults,
                                                      int32_t* __restrict__ out_counts, int32_t* __restrict__ out_lhs,
@@ -420,16 +549,17 @@ __global__ __launch_bounds__(1024) void k_ch_compact(const CascadePair* __restri
       j[k] = 0;
       d[k] = 0.0f;
       if (i < P.na) {
-        const uint4 t = reinterpret_cast<const uint4*>(P.slots_a + (size_t)i * SLOT_WORDS)[3];   // best lo, best hi, -, -
-        const int take = (int)P.slots_a[(size_t)i * SLOT_WORDS + SLOT_TAKE];
-        if (take >= 0) {
+        uint32_t* sa = P.slots_a + (size_t)i * SLOT_WORDS;
+        const uint4 t = reinterpret_cast<const uint4*>(sa)[3];   // state, -, best (inverted) low, high
+        if (t.x != 0) clear_slot(sa);                            // only this thread ever reads slot i
+        if (t.x >= STATE_MATCH) {
           nfwd++;
-          j[k] = (int)t.x;
-          d[k] = __uint_as_float(t.y);
+          j[k] = (int)~t.z;
+          d[k] = __uint_as_float(~t.w);
           keep[k] = true;
           if (cross_check) {
-            const uint32_t* sb = P.slots_b + (size_t)j[k] * SLOT_WORDS;
-            keep[k] = (int)sb[SLOT_TAKE] >= 0 && (int)sb[SLOT_BEST] == i;
+            const uint4 u = reinterpret_cast<const uint4*>(P.slots_b + (size_t)j[k] * SLOT_WORDS)[3];
+            keep[k] = u.x >= STATE_MATCH && (int)~u.z == i;
           }
         }
       }
@@ -474,10 +604,26 @@ __global__ __launch_bounds__(1024) void k_ch_compact(const CascadePair* __restri
     }
     __syncthreads();
   }
+  // the second image's slots were read by any thread above: cleared only now
+  if (cross_check) {
+    for (int q = tid; q < P.nb; q += 1024) {
+      uint32_t* sb = P.slots_b + (size_t)q * SLOT_WORDS;
+      if (sb[SLOT_STATE] != 0) clear_slot(sb);
+    }
+  }
   if (tid == 0) {
     out_counts[P.out_slot] = base_keep;
     out_defaults[P.out_slot] = cross_check ? base_fwd : 0;
+    *P.list_count = 0;
   }
+}
+
+// Number of non-zero words in a buffer that should be all zeros (the work space between batches).
+__global__ __launch_bounds__(256) void k_ch_count_nonzero(const uint32_t* __restrict__ words, size_t n,
+                                                          unsigned long long* __restrict__ out) {
+  unsigned long long mine = 0;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) mine += words[k] != 0;
+  if (mine) atomicAdd(out, mine);
 }
 
 }  // namespace sfm_cascade

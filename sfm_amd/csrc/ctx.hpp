@@ -24,8 +24,9 @@ struct Image {
   // cascade-hash state (sfm_hip_cascade_hash_images): one allocation holding the hash records in
   // image order, the six copies sorted by bucket, and the bucket offsets
   void* hash_block = nullptr;
-  void* hash_recs = nullptr;      // [n] records of 32 bytes
-  void* hash_grouped = nullptr;   // [6][n] records, group g sorted by its bucket id, then by index
+  void* hash_recs = nullptr;      // [n] records of 32 bytes, image order
+  void* hash_gcodes = nullptr;    // [6][n] hash codes, group g sorted by its bucket id, then by index
+  void* hash_gmeta = nullptr;     // [6][n] bucket ids + index, same order
   int32_t* hash_offsets = nullptr;  // [6][1025]
 };
 
@@ -46,7 +47,10 @@ struct Lane {
   hipStream_t stream = nullptr;
   // grow-only device work space
   DevBuf tables_dev, rowpart, colpart, best, out_dev;
-  DevBuf cascade_tables, cascade_slots;          // cascade-hash matcher: pair table, per-query slots
+  // cascade-hash matcher: pair table, per-query slots + list counters (all zeros between batches),
+  // close-pair lists
+  DevBuf cascade_tables, cascade_slots, cascade_lists;
+  bool cascade_slots_dirty = false;              // a batch was abandoned half queued: clear before the next
   std::vector<char> tables_shadow;               // what tables_dev currently holds
   // pinned staging for the per-batch tables, two slots
   void* stage_host[2] = {nullptr, nullptr};
@@ -82,6 +86,7 @@ struct sfm_hip_ctx {
   // cascade-hash matcher
   float* cascade_projection = nullptr;   // device: [128 + 60][128] projection rows, then the 128-float mean
   bool cascade_has_projection = false;
+  unsigned long long* cascade_counters = nullptr;   // device: {pairs whose list overflowed, scratch for checks}
   std::vector<hipEvent_t> cascade_timing;   // start/stop pairs of timed cascade match batches
   sfm_hip_cascade_stats cascade_stats{};
 };
@@ -140,7 +145,8 @@ inline void free_image_hashes(Image& im) {
   if (im.hash_block) (void)hipFree(im.hash_block);
   im.hash_block = nullptr;
   im.hash_recs = nullptr;
-  im.hash_grouped = nullptr;
+  im.hash_gcodes = nullptr;
+  im.hash_gmeta = nullptr;
   im.hash_offsets = nullptr;
 }
 

@@ -163,7 +163,7 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
     if (l.stream) (void)hipStreamSynchronize(l.stream);
   for (auto& kv : ctx->images) free_image(kv.second);
   for (Lane& l : ctx->lanes) {
-    for (DevBuf* b : {&l.tables_dev, &l.rowpart, &l.colpart, &l.best, &l.out_dev, &l.cascade_tables, &l.cascade_slots})
+    for (DevBuf* b : {&l.tables_dev, &l.rowpart, &l.colpart, &l.best, &l.out_dev, &l.cascade_tables, &l.cascade_slots, &l.cascade_lists})
       if (b->p) (void)hipFree(b->p);
     for (int s = 0; s < 2; s++) {
       if (l.stage_host[s]) (void)hipHostFree(l.stage_host[s]);
@@ -174,6 +174,7 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
   if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
   if (ctx->cascade_projection) (void)hipFree(ctx->cascade_projection);
+  if (ctx->cascade_counters) (void)hipFree(ctx->cascade_counters);
   for (auto e : ctx->cascade_timing) (void)hipEventDestroy(e);
   for (auto& t : ctx->timed) {
     (void)hipEventDestroy(t.start);

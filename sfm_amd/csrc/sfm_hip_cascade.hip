@@ -20,6 +20,13 @@ constexpr size_t PROJ_FLOATS = (size_t)(NPROJ + 1) * DIM;   // projection rows, 
 constexpr int MAX_PAIRS_PER_BATCH = 1024;
 constexpr size_t SLOT_BYTES_PER_BATCH = (size_t)2 << 30;
 
+constexpr int NEAREST_BLOCKS = 8;    // workgroups striding one pair's list
+constexpr int FALLBACK_BLOCKS = 8;   // workgroups striding one pair's queries / records on the list-free path
+
+// Close pairs a pair's list can hold.  Descriptors with a near-duplicate in the other image have a
+// few each; a pair that needs more is matched without the list (slower, same result).
+size_t list_capacity(int32_t na, int32_t nb) { return (size_t)8 * (size_t)std::max(na, nb) + 1024; }
+
 struct Scratch {   // a device allocation that lives for one call
   void* p = nullptr;
   ~Scratch() {
@@ -131,21 +138,26 @@ int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
   for (Image* im : ims) {
     free_image_hashes(*im);
     const size_t n = (size_t)im->n;
+    if (n >= (size_t)MAX_IMAGE_ROWS)
+      return fail(ctx, SFM_HIP_ERR_INVALID, "the cascade-hash path takes images of fewer than 2^28 descriptors");
     const size_t recs_bytes = align_up(std::max<size_t>(n, 1) * sizeof(HashRec), 256);
-    const size_t grouped_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(HashRec), 256);
+    const size_t codes_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(uint4), 256);
+    const size_t meta_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(HashMeta), 256);
     const size_t off_bytes = align_up((size_t)GROUPS * (BUCKETS + 1) * sizeof(int32_t), 256);
-    hipError_t e = hipMalloc(&im->hash_block, recs_bytes + grouped_bytes + off_bytes);
+    hipError_t e = hipMalloc(&im->hash_block, recs_bytes + codes_bytes + meta_bytes + off_bytes);
     if (e != hipSuccess) {
       im->hash_block = nullptr;
       return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc hash records: ") + hipGetErrorString(e));
     }
     im->hash_recs = im->hash_block;
-    im->hash_grouped = (char*)im->hash_block + recs_bytes;
-    im->hash_offsets = (int32_t*)((char*)im->hash_block + recs_bytes + grouped_bytes);
+    im->hash_gcodes = (char*)im->hash_block + recs_bytes;
+    im->hash_gmeta = (char*)im->hash_block + recs_bytes + codes_bytes;
+    im->hash_offsets = (int32_t*)((char*)im->hash_block + recs_bytes + codes_bytes + meta_bytes);
     HashJob j;
     j.d = im->d;
     j.recs = (HashRec*)im->hash_recs;
-    j.grouped = (HashRec*)im->hash_grouped;
+    j.gcodes = (uint4*)im->hash_gcodes;
+    j.gmeta = (HashMeta*)im->hash_gmeta;
     j.offsets = im->hash_offsets;
     j.n = im->n;
     j.first_block = blocks;
@@ -211,24 +223,41 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     plan[(size_t)p] = {&ix->second, &iy->second};
   }
 
+  if (!ctx->cascade_counters) {
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->cascade_counters, 2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemset(ctx->cascade_counters, 0, 2 * sizeof(unsigned long long)));
+  }
+
   int done = 0;
   while (done < n_pairs) {
+    // a batch: its per-query slots (64 bytes per descriptor of either image), one list counter per
+    // pair, and the close-pair lists
     int count = 0;
-    size_t slot_bytes = 0;
+    size_t slot_bytes = 0, list_entries = 0;
     while (done + count < n_pairs && count < MAX_PAIRS_PER_BATCH) {
       const auto& pl = plan[(size_t)(done + count)];
       const size_t b = ((size_t)pl.first->n + (size_t)pl.second->n) * SLOT_WORDS * 4;
       if (count > 0 && slot_bytes + b > SLOT_BYTES_PER_BATCH) break;
       slot_bytes += b;
+      list_entries += list_capacity(pl.first->n, pl.second->n);
       count++;
     }
+    const size_t counters_at = align_up(slot_bytes, 256);
+    const size_t zero_bytes = counters_at + align_up((size_t)count * 4, 256);
     Lane& L = ctx->lanes[ctx->next_lane];
     ctx->next_lane = (ctx->next_lane + 1) % N_LANES;
     hipStream_t st = L.stream;
     int rc;
     const size_t table_bytes = sizeof(CascadePair) * (size_t)count;
     if ((rc = ensure(ctx, L, L.cascade_tables, table_bytes))) return rc;
-    if ((rc = ensure(ctx, L, L.cascade_slots, std::max<size_t>(slot_bytes, 256)))) return rc;
+    if ((rc = ensure(ctx, L, L.cascade_lists, std::max<size_t>(list_entries, 1) * sizeof(uint2)))) return rc;
+    // The slots and counters are all zeros between batches (k_ch_compact puts back what a batch
+    // dirtied), so only a new allocation, or one a failed call left half used, is cleared.
+    const size_t slots_before = L.cascade_slots.bytes;
+    if ((rc = ensure(ctx, L, L.cascade_slots, zero_bytes))) return rc;
+    if (L.cascade_slots.bytes != slots_before || L.cascade_slots_dirty)
+      HIP_TRY(ctx, hipMemsetAsync(L.cascade_slots.p, 0, L.cascade_slots.bytes, st));
+    L.cascade_slots_dirty = true;   // until everything below is queued
 
     // Outputs: straight into the caller's buffers when those are pinned host memory, otherwise
     // through a device staging area that is copied back.
@@ -260,15 +289,18 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     if ((rc = ensure_stage(ctx, L, slot, table_bytes))) return rc;
     CascadePair* hp = reinterpret_cast<CascadePair*>(L.stage_host[slot]);
     uint32_t* sp = (uint32_t*)L.cascade_slots.p;
+    uint32_t* counters = (uint32_t*)((char*)L.cascade_slots.p + counters_at);
+    uint2* lp = (uint2*)L.cascade_lists.p;
     int max_na = 0, max_n = 0;
     double bytes = 0.0;
     for (int k = 0; k < count; k++) {
       const Image& X = *plan[(size_t)(done + k)].first;
       const Image& Y = *plan[(size_t)(done + k)].second;
       CascadePair& d = hp[k];
-      d.ga = (const HashRec*)X.hash_grouped;
-      d.gb = (const HashRec*)Y.hash_grouped;
-      d.offa = X.hash_offsets;
+      d.ca = (const uint4*)X.hash_gcodes;
+      d.ma = (const HashMeta*)X.hash_gmeta;
+      d.cb = (const uint4*)Y.hash_gcodes;
+      d.mb = (const HashMeta*)Y.hash_gmeta;
       d.offb = Y.hash_offsets;
       d.da = X.d;
       d.db = Y.d;
@@ -276,16 +308,20 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       sp += (size_t)X.n * SLOT_WORDS;
       d.slots_b = sp;
       sp += (size_t)Y.n * SLOT_WORDS;
+      d.list = lp;
+      d.list_cap = (uint32_t)list_capacity(X.n, Y.n);
+      lp += d.list_cap;
+      d.list_count = counters + k;
       d.na = X.n;
       d.nb = Y.n;
       d.out_slot = k;
-      d.pad_ = 0;
       max_na = std::max(max_na, X.n);
       max_n = std::max(max_n, std::max(X.n, cross_check ? Y.n : 0));
-      const double q = (double)X.n + (double)Y.n;
-      // two walks over the bucket-ordered records of both images; the per-query slots are zeroed,
-      // read and rewritten by the threshold step and read by the compaction
-      bytes += 2.0 * GROUPS * q * sizeof(HashRec) + 3.0 * q * SLOT_WORDS * 4;
+      // what one pair has to read at the least: the first image's bucket-ordered records (codes and
+      // bucket ids, 32 bytes) and the second image's codes (16 bytes) in all six groups, and one
+      // 16-byte result word per descriptor
+      bytes += GROUPS * ((double)X.n * (sizeof(uint4) + sizeof(HashMeta)) + (double)Y.n * sizeof(uint4)) +
+               16.0 * ((double)X.n + (double)Y.n);
     }
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->profiling) {
@@ -295,22 +331,25 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     HIP_TRY(ctx, hipMemcpyAsync(L.cascade_tables.p, hp, table_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipEventRecord(L.stage_free[slot], st));
     if (t0) HIP_TRY(ctx, hipEventRecord(t0, st));
-    if (slot_bytes) HIP_TRY(ctx, hipMemsetAsync(L.cascade_slots.p, 0, slot_bytes, st));
     const CascadePair* dp = (const CascadePair*)L.cascade_tables.p;
     const int both = cross_check ? 1 : 0;
     if (max_na > 0) {
-      const dim3 walk((unsigned)((max_na + 255) / 256), GROUPS, (unsigned)count);
-      const dim3 per_query((unsigned)((max_n + 255) / 256), cross_check ? 2 : 1, (unsigned)count);
-      hipLaunchKernelGGL(k_ch_pairs<PASS_COUNT>, walk, dim3(256), 0, st, dp, both);
+      hipLaunchKernelGGL(k_ch_walk<WALK_COUNT>, dim3((unsigned)((max_na + 255) / 256), GROUPS, (unsigned)count), dim3(256), 0,
+                         st, dp, both);
       HIP_TRY(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_ch_threshold, per_query, dim3(256), 0, st, dp);
+      hipLaunchKernelGGL(k_ch_nearest, dim3(NEAREST_BLOCKS, 1, (unsigned)count), dim3(256), 0, st, dp, both);
       HIP_TRY(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_ch_pairs<PASS_NEAREST>, walk, dim3(256), 0, st, dp, both);
+      // the two kernels below return at once for every pair whose list was complete
+      hipLaunchKernelGGL(k_ch_take_all, dim3(FALLBACK_BLOCKS, cross_check ? 2 : 1, (unsigned)count), dim3(256), 0, st, dp,
+                         ctx->cascade_counters);
+      HIP_TRY(ctx, hipGetLastError());
+      hipLaunchKernelGGL(k_ch_walk<WALK_NEAREST>, dim3(FALLBACK_BLOCKS, GROUPS, (unsigned)count), dim3(256), 0, st, dp, both);
       HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_ch_compact, dim3((unsigned)count), dim3(1024), 0, st, dp, both, k_defaults, k_counts, k_lhs, k_rhs,
                        k_dist, out_stride);
     HIP_TRY(ctx, hipGetLastError());
+    L.cascade_slots_dirty = false;
     if (t1) {
       HIP_TRY(ctx, hipEventRecord(t1, st));
       ctx->cascade_timing.push_back(t0);
@@ -387,6 +426,22 @@ int sfm_hip_cascade_get_stats(sfm_hip_ctx* ctx, sfm_hip_cascade_stats* out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (int rc = sync_all(ctx)) return rc;
   if (int rc = fold_cascade_timing(ctx)) return rc;
+  ctx->cascade_stats.workspace_dirty_words = 0;
+  if (ctx->cascade_counters) {
+    // the work space must be all zeros now that nothing is queued
+    HIP_TRY(ctx, hipMemset(ctx->cascade_counters + 1, 0, sizeof(unsigned long long)));
+    for (Lane& L : ctx->lanes) {
+      if (!L.cascade_slots.p || L.cascade_slots_dirty) continue;
+      hipLaunchKernelGGL(k_ch_count_nonzero, dim3(1024), dim3(256), 0, L.stream, (const uint32_t*)L.cascade_slots.p,
+                         L.cascade_slots.bytes / 4, ctx->cascade_counters + 1);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipStreamSynchronize(L.stream));
+    }
+    unsigned long long c[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(c, ctx->cascade_counters, sizeof(c), hipMemcpyDeviceToHost));
+    ctx->cascade_stats.list_overflows = c[0];
+    ctx->cascade_stats.workspace_dirty_words = c[1];
+  }
   *out = ctx->cascade_stats;
   return SFM_HIP_OK;
 }
@@ -396,6 +451,7 @@ int sfm_hip_cascade_reset_stats(sfm_hip_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (int rc = sync_all(ctx)) return rc;
   if (int rc = fold_cascade_timing(ctx)) return rc;
+  if (ctx->cascade_counters) HIP_TRY(ctx, hipMemset(ctx->cascade_counters, 0, 2 * sizeof(unsigned long long)));
   ctx->cascade_stats = sfm_hip_cascade_stats{};
   return SFM_HIP_OK;
 }

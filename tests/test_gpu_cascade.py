@@ -20,6 +20,8 @@ pytestmark = pytest.mark.gpu
 def matcher():
     m = sfm_amd.Matcher(0)
     yield m
+    # every batch leaves the per-query work space all zeros
+    assert m.cascade_stats()["workspace_dirty_words"] == 0
     m.close()
 
 
@@ -148,8 +150,19 @@ def test_all_identical_descriptors(matcher):
     images = {0: np.repeat(row, 300, axis=0), 1: np.repeat(row, 200, axis=0)}
     _upload(matcher, images)
     matcher.cascade_prepare([(0, 1)])
+    before = matcher.cascade_stats()["list_overflows"]
     for cross in (False, True):
         assert _check_pairs(matcher, images, [(0, 1)], cross) >= 1
+    # 60,000 close pairs do not fit the pair's list: the list-free path answered
+    st = matcher.cascade_stats()
+    assert st["list_overflows"] == before + 2 and st["workspace_dirty_words"] == 0
+    # and an ordinary pair right after it, in the same work space
+    a, b = synth.make_repetitive_set(2, 700, 0.5, 2, seed=12, sigma=0.002)
+    images = {0: a, 1: b}
+    _upload(matcher, images)
+    matcher.cascade_prepare([(0, 1)])
+    assert _check_pairs(matcher, images, [(0, 1)], True) > 20
+    assert matcher.cascade_stats()["list_overflows"] == before + 2
 
 
 def test_empty_and_single_images(matcher):
