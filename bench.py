@@ -24,6 +24,7 @@ N_FEATURES = 8192
 PLANTED = 4096
 PEAK_FP32_MFMA_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_FP16_MFMA_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (dense)
+PEAK_HBM_GBPS = 8000.0          # HBM3E
 
 
 def cpu_baseline(A, B, expected):
@@ -45,6 +46,72 @@ def cpu_baseline(A, B, expected):
             "sample": "one full 8192x8192 pair, ratio 0.8 + cross-check, 2 threads (the reference's pool size)",
             "seconds_per_pair": t2, "matches_equal_gpu": bool(same),
             "all_cores": {"value": 1.0 / t16, "cores": 16, "seconds_per_pair": t16}}
+
+
+def cascade_cpu_baseline(images, pairs, got):
+    """The CPU oracle of the cascade-hash matcher (single-threaded, as the reference runs it) on a
+    bounded sample: the first four images of the set, their six pairs."""
+    from oracle import cascade
+    whole, hash_s, match_s = cascade.match_set(images, pairs, True, threads=1)
+    same = all((nd, l.tolist(), r.tolist()) == (whole[p][0], whole[p][1].tolist(), whole[p][2].tolist())
+               for p, (nd, l, r, _) in zip(pairs, got))
+    return {"value": len(pairs) / match_s, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d images x %d features, %d pairs, cross-check; hashing the images timed apart"
+                      % (len(images), N_FEATURES, len(pairs)),
+            "seconds_per_pair": match_s / len(pairs), "hash_seconds_per_image": hash_s / len(images),
+            "matches_equal_gpu": bool(same)}
+
+
+def cascade_leg(m, with_cpu, n_images=32, reps=10):
+    """The cascade-hash matcher (the one the reference's driver runs) on the same GPU: all pairs of
+    a synthetic set with repeated structure, descriptors and hashes resident.  value counts
+    back-to-back batches; the roofline figure comes from batches run one at a time between HIP
+    events (bytes: the library's count of what a pair has to read at the least)."""
+    import numpy as np
+    from sfm_amd import synth
+    imgs = synth.make_repetitive_set(n_images, N_FEATURES, 0.5, 2, seed=17, sigma=0.002)
+    ids = list(range(100, 100 + n_images))
+    for i, d in zip(ids, imgs):
+        m.upload(i, d)
+    pairs = [(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]]
+    m.cascade_prepare(pairs)
+    t0 = time.perf_counter()
+    m.cascade_prepare(pairs)
+    prepare_s = time.perf_counter() - t0
+    for _ in range(2):
+        out = m.cascade_match_pairs_async(pairs, True, stride=N_FEATURES)
+    m.sync()
+    n_matches, n_defaults = int(out[1].sum()), int(out[0].sum())
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.cascade_match_pairs_async(pairs, True, stride=N_FEATURES)
+    m.sync()
+    value = reps * len(pairs) / (time.perf_counter() - t0)
+    m.set_profiling(True)
+    m.cascade_reset_stats()
+    for _ in range(reps):
+        m.cascade_match_pairs_async(pairs, True, stride=N_FEATURES)
+        m.sync()
+    st = m.cascade_stats()
+    m.set_profiling(False)
+    gbps = st["match_bytes"] / (st["match_ms"] * 1e-3) / 1e9
+    leg = {"matcher": "cascade hash", "value": value, "unit": "pairs/s",
+           "workload": "%d synthetic images x %d features with repeated structure, all %d pairs, cross-check"
+                       % (n_images, N_FEATURES, len(pairs)),
+           "matches": n_matches, "default_records": n_defaults,
+           "prepare_seconds_all_images": prepare_s, "list_overflows": st["list_overflows"],
+           "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                        "traffic": None, "kernel": "one batch, k_ch_walk<COUNT> .. k_ch_compact",
+                        "avg_batch_ms": st["match_ms"] / st["match_launches"],
+                        "bytes_per_pair": st["match_bytes"] / (reps * len(pairs))}}
+    if with_cpu:
+        sub = {i: d for i, d in zip(ids[:4], imgs[:4])}
+        sp = [(a, b) for k, a in enumerate(ids[:4]) for b in ids[k + 1:4]]
+        m.cascade_prepare(sp)       # the mean vector is taken over the images that take part
+        leg["cpu_baseline"] = cascade_cpu_baseline(sub, sp, m.cascade_match_pairs(sp, True))
+    for i in ids:
+        m.drop(i)
+    return leg
 
 
 def replication_check(m, rank, world, local_rank, barrier, n_images=64):
@@ -114,6 +181,8 @@ def main():
     ap.add_argument("--replication-check", action="store_true",
                     help="N > 1: also time host uploads against the RCCL all-gather of a descriptor set "
                          "(outside the timed region; adds collectives to the run, hence opt-in)")
+    ap.add_argument("--no-cascade", action="store_true",
+                    help="do not time the cascade-hash matcher after the main run")
     ap.add_argument("--untimed-pass", action="store_true",
                     help="after the timed region, run the same K steps once more without per-launch kernel "
                          "timing and report that rate as an extra field")
@@ -244,6 +313,11 @@ def main():
                 "matches_equal_main_engine": bool(same), "roofline": roofline(o_st, other, None)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, B, got)
+        if world == 1 and not args.no_cascade:
+            try:
+                line["cascade_hash"] = cascade_leg(m, not args.no_cpu_baseline)
+            except Exception as e:   # an extra, never the reason the headline line is lost
+                line["cascade_hash"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line), flush=True)
 
     m.close()

@@ -415,7 +415,11 @@ __global__ __launch_bounds__(256) void k_ch_walk(const CascadePair* __restrict__
       const int cnt = min(WALK_CHUNK, hi - c0);
       for (int r = tid; r < cnt; r += 256) stage[r] = cb[c0 + r];
       __syncthreads();
+#ifdef SFM_ABLATE_WALK_LOOP   // timing experiments only (tools/build_variant.sh)
+      const int q1 = 0;
+#else
       const int q1 = min(e, c0 + cnt);
+#endif
       for (int q = max(s, c0); q < q1; q++) {
         const uint4 t = stage[q - c0];
         const uint32_t h = __popc(code.x ^ t.x) + __popc(code.y ^ t.y) + __popc(code.z ^ t.z) + __popc(code.w ^ t.w);
@@ -430,6 +434,9 @@ __global__ __launch_bounds__(256) void k_ch_walk(const CascadePair* __restrict__
         if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
         if (earlier) continue;
         const uint32_t i = meta.idx, j = other.idx;
+#ifdef SFM_ABLATE_WALK_EMIT
+        if (h != 77) continue;
+#endif
         if (MODE == WALK_COUNT) {
           atomicAdd(P.slots_a + (size_t)i * SLOT_WORDS + SLOT_HIST + h, 1u);
           if (both_directions) atomicAdd(P.slots_b + (size_t)j * SLOT_WORDS + SLOT_HIST + h, 1u);

@@ -67,4 +67,4 @@ def test_product_code_never_touches_the_oracle():
     bench = open(os.path.join(ROOT, "bench.py")).read()
     uses = [i for i, line in enumerate(bench.split("\n")) if "oracle" in line and "import" in line]
     body = bench[bench.index("def cpu_baseline"):bench.index("def replication_check")]
-    assert len(uses) == 1 and "from oracle import oracle" in body
+    assert len(uses) == 2 and "from oracle import oracle" in body and "from oracle import cascade" in body
