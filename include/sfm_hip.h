@@ -170,9 +170,8 @@ typedef struct {
   double match_ms;          /* their summed duration on the GPU, first kernel to last (HIP events on
                                the stream they run on; only while profiling is enabled) */
   double match_bytes;       /* bytes those batches had to read at the least: per pair the bucket-ordered
-                               hash records of both images once (6 groups x (48 bytes per descriptor
-                               of the first image + 16 per descriptor of the second)) and one
-                               16-byte result word per descriptor */
+                               hash records of both images once (6 groups x 32 bytes per descriptor)
+                               and one 16-byte result word per descriptor */
   uint64_t list_overflows;  /* pairs with more close candidate pairs than their list holds, matched by
                                the slower path that needs no list */
   uint64_t workspace_dirty_words; /* non-zero words found in the per-query work space, which every
@@ -196,7 +195,8 @@ int sfm_hip_cascade_column_sums(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
  * vector mean128 subtracted from every descriptor (.cc:21): 128-bit hash codes, six 10-bit bucket
  * ids per descriptor, and per group the descriptors sorted by bucket (ascending index inside a
  * bucket, as .cc:43-46 fills them).  Results stay on the GPU.  Hashing an image again replaces its
- * hashes; uploading an image again discards them.  Blocking. */
+ * hashes; uploading an image again discards them.  Images of more than 262,144 descriptors are
+ * refused.  Blocking. */
 int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int32_t n_images, const float* mean128);
 
 /* Copy one image's hashes to the host: codes n x 4 words (hash bit j is bit j % 32 of word j / 32),

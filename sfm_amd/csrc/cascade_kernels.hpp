@@ -7,7 +7,7 @@
 //   k_ch_group    per group a copy of the hash records sorted by bucket (stable: ascending index
 //                 inside a bucket, the order .cc:43-46 fills them in) + bucket offsets
 // Per pair (DescriptorMath both ways + cross-check, .cc:51-116, :173-195):
-//   k_ch_walk<COUNT>     walk every (first-image descriptor, second-image descriptor) that share a
+//   k_ch_walk_count      walk every (first-image descriptor, second-image descriptor) that share a
 //                        bucket; those within Hamming distance 10 ("close pairs") are counted into
 //                        both descriptors' Hamming histograms and appended to the pair's list
 //   k_ch_nearest         per close pair of the list: how many Hamming bins the reference would take
@@ -18,7 +18,7 @@
 // and, only for a pair whose close pairs did not fit its list (whole images of near-identical
 // descriptors), the same result without the list:
 //   k_ch_take_all        the bins decision for every query of the pair
-//   k_ch_walk<NEAREST>   the walk again, distances computed on the way
+//   k_ch_walk_nearest    the walk again, distances computed on the way
 //
 // Why the walk is by bucket and not by query as in the reference: "i and j share a bucket of group g"
 // and the Hamming distance are symmetric, so one walk serves both directions, and with the records
@@ -74,7 +74,7 @@ constexpr uint32_t STATE_NONE = 1;
 constexpr uint32_t STATE_MATCH = 2;
 
 constexpr int LIST_H_SHIFT = 28;   // list entries: {i, j | h << 28}
-constexpr int MAX_IMAGE_ROWS = 1 << LIST_H_SHIFT;
+constexpr int MAX_IMAGE_ROWS = 1 << 18;   // k_ch_nearest lays out one count per 256 first-image records and group in LDS
 
 struct ImageRef {
   const float* d;
@@ -97,14 +97,15 @@ struct CascadePair {
   const HashMeta* ma;    //              bucket ids + index, [6][na]
   const uint4* cb;       // second image
   const HashMeta* mb;
-  const int32_t* offb;   // second image: bucket offsets [6][1025]
+  const int32_t* offa;   // bucket offsets [6][1025]
+  const int32_t* offb;
   const float* da;       // descriptor rows
   const float* db;
   uint32_t* slots_a;     // [na][16]
   uint32_t* slots_b;     // [nb][16]
-  uint2* list;           // close pairs {i, j | h << 28}
-  uint32_t* list_count;  // how many were found (may exceed list_cap: then the list is incomplete)
-  uint32_t list_cap;
+  uint2* list;           // close pairs {i, j | h << 28}: one segment of LIST_SEGMENT entries per walk workgroup
+  uint32_t* seg_counts;  // entries in each segment; rewritten by every walk
+  uint32_t* overflow;    // non-zero: some segment was too small, the list is incomplete (zero between batches)
   int32_t na, nb;
   int32_t out_slot;
 };
@@ -359,72 +360,103 @@ __device__ __forceinline__ void fold_distance(const CascadePair& P, uint32_t i, 
 
 // ---------------------------------------------------------------------------------------------
 // The walk over bucket-sharing descriptor pairs.  A workgroup takes 256 consecutive records of the
-// first image in group g's bucket order; the buckets they sit in are consecutive, so the records of
-// the second image they have to meet form ONE contiguous run, which the workgroup stages in LDS
-// (codes only, 16 bytes each) and every thread then scans the part that is its own bucket.  A pair
-// that shares buckets in several groups is handled in the lowest such group only: that is the
-// reference's "seen" map (cascade_hash_matcher.cc:84-86) without its visiting order.
+// first image in group g's bucket order, one per thread; the buckets they sit in are consecutive,
+// so the records of the second image they have to meet form ONE contiguous run, which the
+// workgroup stages in LDS, and every thread scans the part of it that is its own bucket.
+// The scan is bound by instruction issue, so it looks at the low 64 bits of the hash codes first,
+// two candidates per step: two codes that differ in more than ten of those bits (practically every
+// candidate) are done after two XORs and two population counts each.
+// The close pairs found go to a segment of the pair's list that belongs to this workgroup alone:
+// nothing is reserved through an atomic and nothing waits for one.
+// A pair that shares buckets in several groups is handled in the lowest such group only: that is
+// the reference's "seen" map (cascade_hash_matcher.cc:84-86) without its visiting order.
 //   COUNT    close pairs (Hamming distance <= 10; .cc:95 never reads further) go into both
-//            descriptors' histograms (.cc:88-91) and, through a list in LDS, into the pair's list
+//            descriptors' histograms (.cc:88-91) and into the workgroup's list segment
 //   NEAREST  only for a pair whose list overflowed: distances computed on the way (states from
 //            k_ch_take_all)
-// grid: (blocks, 6, pairs); a workgroup loops when blocks * 256 < na.
 // ---------------------------------------------------------------------------------------------
 constexpr int WALK_COUNT = 0;
 constexpr int WALK_NEAREST = 1;
-constexpr int WALK_CHUNK = 512;     // staged records per step
-constexpr int WALK_FOUND = 1024;    // close pairs a workgroup keeps in LDS before it appends them
+constexpr int WALK_THREADS = 256;
+constexpr int WALK_CHUNK = 512;      // staged records of the second image per step
+constexpr int LIST_SEGMENT = 128;    // close pairs a workgroup can report
 
+struct WalkShared {
+  uint2 lo[WALK_CHUNK + 2];     // low halves of the staged codes (+2: the scan reads in twos)
+  uint2 hi[WALK_CHUNK];
+  HashMeta meta[WALK_CHUNK];
+  uint2 found[LIST_SEGMENT];
+  int range[2];
+  uint32_t n_found;
+};
+
+// The work of workgroup bx of nbx for (pair P, group g).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ch_walk(const CascadePair* __restrict__ pairs, int both_directions) {
-  __shared__ uint4 stage[WALK_CHUNK];
-  __shared__ uint2 found[MODE == WALK_COUNT ? WALK_FOUND : 1];
-  __shared__ int range[2];
-  __shared__ uint32_t n_found, list_base;
-  const CascadePair& P = pairs[blockIdx.z];
+__device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, int nbx, int both_directions,
+                                           WalkShared& sh) {
+  uint2* stage_lo = sh.lo;
+  uint2* stage_hi = sh.hi;
+  HashMeta* stage_meta = sh.meta;
+  uint2* found = sh.found;
+  int* range = sh.range;
+  uint32_t& n_found = sh.n_found;
   const int na = P.na, nb = P.nb;
-  if (MODE == WALK_NEAREST && *P.list_count <= P.list_cap) return;   // the list was complete
-  const int g = blockIdx.y;
   const int tid = threadIdx.x;
-  const uint4* ca = P.ca + (size_t)g * (size_t)na;
-  const HashMeta* ma = P.ma + (size_t)g * (size_t)na;
+  const int p0 = bx * WALK_THREADS;
+  const uint32_t seg = (uint32_t)g * (uint32_t)nbx + (uint32_t)bx;
+  if (p0 >= na) {
+    if (MODE == WALK_COUNT && tid == 0) P.seg_counts[seg] = 0;
+    return;
+  }
   const uint4* cb = P.cb + (size_t)g * (size_t)nb;
   const HashMeta* mb = P.mb + (size_t)g * (size_t)nb;
   const int32_t* off = P.offb + (size_t)g * (BUCKETS + 1);
-  for (int p0 = blockIdx.x * 256; p0 < na; p0 += gridDim.x * 256) {
-    const int p = p0 + tid;
-    const bool valid = p < na;
-    uint4 code = make_uint4(0, 0, 0, 0);
-    HashMeta meta{};
-    int s = 0, e = 0;
-    if (valid) {
-      code = ca[p];
-      meta = ma[p];
-      const uint32_t b = (meta.bids[g >> 1] >> ((g & 1) * 16)) & 0xFFFFu;
-      s = off[b];
-      e = off[b + 1];
+  const int p = p0 + tid;
+  const bool valid = p < na;
+  uint4 code = make_uint4(0, 0, 0, 0);
+  HashMeta meta{};
+  int s = 0, e = 0;
+  if (valid) {
+    code = P.ca[(size_t)g * (size_t)na + p];
+    meta = P.ma[(size_t)g * (size_t)na + p];
+    const uint32_t b = (meta.bids[g >> 1] >> ((g & 1) * 16)) & 0xFFFFu;
+    s = off[b];
+    e = off[b + 1];
+  }
+  if (tid == 0) {
+    range[0] = s;
+    n_found = 0;
+  }
+  if (p == min(p0 + WALK_THREADS - 1, na - 1)) range[1] = e;
+  __syncthreads();
+  const int lo = range[0], hi = range[1];
+  for (int c0 = lo; c0 < hi; c0 += WALK_CHUNK) {
+    const int cnt = min(WALK_CHUNK, hi - c0);
+    for (int r = tid; r < cnt; r += WALK_THREADS) {
+      const uint4 c = cb[c0 + r];
+      stage_lo[r] = make_uint2(c.x, c.y);
+      stage_hi[r] = make_uint2(c.z, c.w);
+      stage_meta[r] = mb[c0 + r];
     }
-    if (tid == 0) {
-      range[0] = s;
-      n_found = 0;
-    }
-    if (p == min(p0 + 255, na - 1)) range[1] = e;
     __syncthreads();
-    const int lo = range[0], hi = range[1];
-    for (int c0 = lo; c0 < hi; c0 += WALK_CHUNK) {
-      const int cnt = min(WALK_CHUNK, hi - c0);
-      for (int r = tid; r < cnt; r += 256) stage[r] = cb[c0 + r];
-      __syncthreads();
 #ifdef SFM_ABLATE_WALK_LOOP   // timing experiments only (tools/build_variant.sh)
-      const int q1 = 0;
+    const int q1 = 0;
 #else
-      const int q1 = min(e, c0 + cnt);
+    const int q1 = min(e, c0 + cnt);
 #endif
-      for (int q = max(s, c0); q < q1; q++) {
-        const uint4 t = stage[q - c0];
-        const uint32_t h = __popc(code.x ^ t.x) + __popc(code.y ^ t.y) + __popc(code.z ^ t.z) + __popc(code.w ^ t.w);
+    for (int q = max(s, c0); q < q1; q += 2) {
+      const uint2 t0 = stage_lo[q - c0], t1 = stage_lo[q - c0 + 1];
+      const uint32_t l0 = __popc(code.x ^ t0.x) + __popc(code.y ^ t0.y);
+      const uint32_t l1 = q + 1 < q1 ? __popc(code.x ^ t1.x) + __popc(code.y ^ t1.y) : 99u;
+      if (min(l0, l1) > (uint32_t)MAX_HAMMING) continue;
+      for (int k = 0; k < 2; k++) {
+        const uint32_t low = k ? l1 : l0;
+        if (low > (uint32_t)MAX_HAMMING) continue;
+        const int r = q - c0 + k;
+        const uint2 th = stage_hi[r];
+        const uint32_t h = low + __popc(code.z ^ th.x) + __popc(code.w ^ th.y);
         if (h > (uint32_t)MAX_HAMMING) continue;
-        const HashMeta other = mb[q];
+        const HashMeta other = stage_meta[r];
         const uint32_t x0 = meta.bids[0] ^ other.bids[0], x1 = meta.bids[1] ^ other.bids[1], x2 = meta.bids[2] ^ other.bids[2];
         bool earlier = false;   // shares a bucket in a group before g: counted there
         if (g > 0) earlier |= (x0 & 0xFFFFu) == 0;
@@ -434,54 +466,103 @@ __global__ __launch_bounds__(256) void k_ch_walk(const CascadePair* __restrict__
         if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
         if (earlier) continue;
         const uint32_t i = meta.idx, j = other.idx;
-#ifdef SFM_ABLATE_WALK_EMIT
-        if (h != 77) continue;
-#endif
         if (MODE == WALK_COUNT) {
+#ifndef SFM_ABLATE_WALK_HIST
           atomicAdd(P.slots_a + (size_t)i * SLOT_WORDS + SLOT_HIST + h, 1u);
           if (both_directions) atomicAdd(P.slots_b + (size_t)j * SLOT_WORDS + SLOT_HIST + h, 1u);
-          const uint2 entry = make_uint2(i, j | (h << LIST_H_SHIFT));
-          const uint32_t k = atomicAdd(&n_found, 1u);
-          if (k < (uint32_t)WALK_FOUND) {
-            found[k] = entry;
-          } else {   // more than the workgroup can hold: straight to the pair's list
-            const uint32_t at = atomicAdd(P.list_count, 1u);
-            if (at < P.list_cap) P.list[at] = entry;
-          }
+#endif
+          const uint32_t at = atomicAdd(&n_found, 1u);
+          if (at < (uint32_t)LIST_SEGMENT) found[at] = make_uint2(i, j | (h << LIST_H_SHIFT));
         } else {
           const bool fa = inside_taken_bins(P.slots_a[(size_t)i * SLOT_WORDS + SLOT_STATE], h);
           const bool fb = both_directions && inside_taken_bins(P.slots_b[(size_t)j * SLOT_WORDS + SLOT_STATE], h);
           if (fa || fb) fold_distance(P, i, j, fa, fb);
         }
       }
-      __syncthreads();
     }
-    if (MODE == WALK_COUNT) {
-      const uint32_t mine = min(n_found, (uint32_t)WALK_FOUND);
-      if (mine) {
-        if (tid == 0) list_base = atomicAdd(P.list_count, mine);
-        __syncthreads();
-        for (uint32_t k = tid; k < mine; k += 256) {
-          const uint32_t at = list_base + k;
-          if (at < P.list_cap) P.list[at] = found[k];
-        }
-      }
-    }
-    __syncthreads();   // range[], n_found and found[] are rewritten by the next round
+    __syncthreads();
   }
+  if (MODE == WALK_COUNT) {
+    // no round trip here: the segment is this workgroup's own
+    const uint32_t total = n_found;
+    const uint32_t mine = min(total, (uint32_t)LIST_SEGMENT);
+    uint2* out = P.list + (size_t)seg * LIST_SEGMENT;
+    for (uint32_t k = tid; k < mine; k += WALK_THREADS) out[k] = found[k];
+    if (tid == 0) {
+      P.seg_counts[seg] = mine;
+      if (total > (uint32_t)LIST_SEGMENT) *P.overflow = 1;
+    }
+  }
+  __syncthreads();   // the shared arrays are free again
+}
+
+// COUNT: grid (ceil(largest na of the batch / 256), 6, pairs), one workgroup per 256 records.
+__global__ __launch_bounds__(WALK_THREADS) void k_ch_walk_count(const CascadePair* __restrict__ pairs, int both_directions) {
+  __shared__ WalkShared sh;
+  walk_block<WALK_COUNT>(pairs[blockIdx.z], blockIdx.y, blockIdx.x, gridDim.x, both_directions, sh);
+}
+
+// NEAREST: grid (a few, 6, pairs); returns at once unless the pair's list overflowed, else the
+// workgroups stride the pair's records.
+__global__ __launch_bounds__(WALK_THREADS) void k_ch_walk_nearest(const CascadePair* __restrict__ pairs, int both_directions) {
+  __shared__ WalkShared sh;
+  const CascadePair& P = pairs[blockIdx.z];
+  if (*P.overflow == 0) return;
+  const int nbx = (P.na + WALK_THREADS - 1) / WALK_THREADS;
+  for (int bx = blockIdx.x; bx < nbx; bx += gridDim.x) walk_block<WALK_NEAREST>(P, blockIdx.y, bx, nbx, both_directions, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
 // One thread per close pair of a pair's list: the state of both descriptors from their histograms
 // (every thread that names a descriptor stores the same value), then, if the pair lies inside the
-// bins taken for either of them, its distance.  grid: (blocks, 1, pairs), threads stride the list.
+// bins taken for either of them, its distance.  grid: (blocks, 1, pairs); the workgroup lays the
+// segments' counts end to end and its threads stride the entries.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ch_nearest(const CascadePair* __restrict__ pairs, int both_directions) {
+constexpr int NEAREST_MAX_SEGMENTS = GROUPS * (MAX_IMAGE_ROWS / 256);
+
+__global__ __launch_bounds__(256) void k_ch_nearest(const CascadePair* __restrict__ pairs, int both_directions,
+                                                    int segments) {
+  __shared__ uint32_t start[NEAREST_MAX_SEGMENTS + 1];   // start[s] = entries in the segments before s
+  __shared__ uint32_t wave_sum[4];
   const CascadePair& P = pairs[blockIdx.z];
-  const uint32_t total = *P.list_count;
-  if (total > P.list_cap) return;   // incomplete list: k_ch_take_all + k_ch_walk<NEAREST> do this pair
-  for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
-    const uint2 entry = P.list[k];
+  if (*P.overflow != 0) return;   // incomplete list: k_ch_take_all + k_ch_walk_nearest do this pair
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // exclusive scan of the counts: consecutive runs of `per` segments per thread
+  const int per = (segments + 255) / 256;
+  uint32_t mine = 0;
+  for (int k = 0; k < per; k++) {
+    const int sgm = tid * per + k;
+    if (sgm < segments) mine += P.seg_counts[sgm];
+  }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wave_sum[wv] = incl;
+  __syncthreads();
+  uint32_t before = incl - mine;
+  for (int k = 0; k < wv; k++) before += wave_sum[k];
+  for (int k = 0; k < per; k++) {
+    const int sgm = tid * per + k;
+    if (sgm < segments) {
+      start[sgm] = before;
+      before += P.seg_counts[sgm];
+    }
+  }
+  if (tid == 255) start[segments] = before;   // the last thread ends up with the total
+  __syncthreads();
+  const uint32_t total = start[segments];
+  for (uint32_t k = blockIdx.x * 256 + tid; k < total; k += gridDim.x * 256) {
+    // the segment that holds entry k: the last one that starts at or before k
+    int lo = 0, hi = segments - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (start[mid] <= k) lo = mid;
+      else hi = mid - 1;
+    }
+    const uint2 entry = P.list[(size_t)lo * LIST_SEGMENT + (k - start[lo])];
     const uint32_t i = entry.x, j = entry.y & ((1u << LIST_H_SHIFT) - 1u), h = entry.y >> LIST_H_SHIFT;
     uint32_t* sa = P.slots_a + (size_t)i * SLOT_WORDS;
     const uint32_t state_a = take_state(sa);
@@ -503,7 +584,7 @@ __global__ __launch_bounds__(256) void k_ch_nearest(const CascadePair* __restric
 __global__ __launch_bounds__(256) void k_ch_take_all(const CascadePair* __restrict__ pairs,
                                                      unsigned long long* __restrict__ overflowed_pairs) {
   const CascadePair& P = pairs[blockIdx.z];
-  if (*P.list_count <= P.list_cap) return;
+  if (*P.overflow == 0) return;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(overflowed_pairs, 1ull);
   const int n = blockIdx.y == 0 ? P.na : P.nb;
   uint32_t* slots = blockIdx.y == 0 ? P.slots_a : P.slots_b;
@@ -521,7 +602,7 @@ __global__ __launch_bounds__(256) void k_ch_take_all(const CascadePair* __restri
 // threads per pair, eight consecutive queries per thread and sweep: output order is ascending
 // lhs index.  out_defaults: the records `Matches temp(matches.size())` holds before the survivors
 // are appended (.cc:187) -- one per forward match, cross-check only.  Every slot that was touched
-// goes back to zero, and so does the list counter.
+// goes back to zero, and so does the list's overflow mark.
 __device__ __forceinline__ void clear_slot(uint32_t* slot) {
   const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -621,7 +702,7 @@ __global__ __launch_bounds__(1024) void k_ch_compact(const CascadePair* __restri
   if (tid == 0) {
     out_counts[P.out_slot] = base_keep;
     out_defaults[P.out_slot] = cross_check ? base_fwd : 0;
-    *P.list_count = 0;
+    *P.overflow = 0;
   }
 }
 

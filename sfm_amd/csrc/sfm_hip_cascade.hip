@@ -19,13 +19,14 @@ namespace {
 constexpr size_t PROJ_FLOATS = (size_t)(NPROJ + 1) * DIM;   // projection rows, then the mean
 constexpr int MAX_PAIRS_PER_BATCH = 1024;
 constexpr size_t SLOT_BYTES_PER_BATCH = (size_t)2 << 30;
+constexpr size_t LIST_BYTES_PER_BATCH = (size_t)1 << 30;
 
 constexpr int NEAREST_BLOCKS = 8;    // workgroups striding one pair's list
 constexpr int FALLBACK_BLOCKS = 8;   // workgroups striding one pair's queries / records on the list-free path
 
-// Close pairs a pair's list can hold.  Descriptors with a near-duplicate in the other image have a
-// few each; a pair that needs more is matched without the list (slower, same result).
-size_t list_capacity(int32_t na, int32_t nb) { return (size_t)8 * (size_t)std::max(na, nb) + 1024; }
+// Workgroups per (pair, group) of the bucket walk: one per 256 records of the largest first image
+// of the batch (k_ch_walk).
+int walk_blocks(int max_na) { return std::max(1, (max_na + WALK_THREADS - 1) / WALK_THREADS); }
 
 struct Scratch {   // a device allocation that lives for one call
   void* p = nullptr;
@@ -138,8 +139,8 @@ int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
   for (Image* im : ims) {
     free_image_hashes(*im);
     const size_t n = (size_t)im->n;
-    if (n >= (size_t)MAX_IMAGE_ROWS)
-      return fail(ctx, SFM_HIP_ERR_INVALID, "the cascade-hash path takes images of fewer than 2^28 descriptors");
+    if (n > (size_t)MAX_IMAGE_ROWS)
+      return fail(ctx, SFM_HIP_ERR_INVALID, "the cascade-hash path takes images of at most 262,144 descriptors");
     const size_t recs_bytes = align_up(std::max<size_t>(n, 1) * sizeof(HashRec), 256);
     const size_t codes_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(uint4), 256);
     const size_t meta_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(HashMeta), 256);
@@ -230,18 +231,23 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
 
   int done = 0;
   while (done < n_pairs) {
-    // a batch: its per-query slots (64 bytes per descriptor of either image), one list counter per
+    // a batch: its per-query slots (64 bytes per descriptor of either image), one overflow mark per
     // pair, and the close-pair lists
-    int count = 0;
-    size_t slot_bytes = 0, list_entries = 0;
+    int count = 0, batch_max_na = 0;
+    size_t slot_bytes = 0;
     while (done + count < n_pairs && count < MAX_PAIRS_PER_BATCH) {
       const auto& pl = plan[(size_t)(done + count)];
       const size_t b = ((size_t)pl.first->n + (size_t)pl.second->n) * SLOT_WORDS * 4;
-      if (count > 0 && slot_bytes + b > SLOT_BYTES_PER_BATCH) break;
+      const int mx = std::max(batch_max_na, pl.first->n);
+      const size_t lists = (size_t)(count + 1) * GROUPS * walk_blocks(mx) * LIST_SEGMENT * sizeof(uint2);
+      if (count > 0 && (slot_bytes + b > SLOT_BYTES_PER_BATCH || lists > LIST_BYTES_PER_BATCH)) break;
       slot_bytes += b;
-      list_entries += list_capacity(pl.first->n, pl.second->n);
+      batch_max_na = mx;
       count++;
     }
+    // every workgroup of the walk owns one segment of its pair's list
+    const int n_walk = walk_blocks(batch_max_na);
+    const size_t segments = (size_t)GROUPS * n_walk;
     const size_t counters_at = align_up(slot_bytes, 256);
     const size_t zero_bytes = counters_at + align_up((size_t)count * 4, 256);
     Lane& L = ctx->lanes[ctx->next_lane];
@@ -250,7 +256,8 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     int rc;
     const size_t table_bytes = sizeof(CascadePair) * (size_t)count;
     if ((rc = ensure(ctx, L, L.cascade_tables, table_bytes))) return rc;
-    if ((rc = ensure(ctx, L, L.cascade_lists, std::max<size_t>(list_entries, 1) * sizeof(uint2)))) return rc;
+    const size_t list_bytes = (size_t)count * segments * LIST_SEGMENT * sizeof(uint2);
+    if ((rc = ensure(ctx, L, L.cascade_lists, list_bytes + (size_t)count * segments * sizeof(uint32_t)))) return rc;
     // The slots and counters are all zeros between batches (k_ch_compact puts back what a batch
     // dirtied), so only a new allocation, or one a failed call left half used, is cleared.
     const size_t slots_before = L.cascade_slots.bytes;
@@ -289,8 +296,9 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     if ((rc = ensure_stage(ctx, L, slot, table_bytes))) return rc;
     CascadePair* hp = reinterpret_cast<CascadePair*>(L.stage_host[slot]);
     uint32_t* sp = (uint32_t*)L.cascade_slots.p;
-    uint32_t* counters = (uint32_t*)((char*)L.cascade_slots.p + counters_at);
+    uint32_t* overflow_marks = (uint32_t*)((char*)L.cascade_slots.p + counters_at);
     uint2* lp = (uint2*)L.cascade_lists.p;
+    uint32_t* seg_counts = (uint32_t*)((char*)L.cascade_lists.p + list_bytes);
     int max_na = 0, max_n = 0;
     double bytes = 0.0;
     for (int k = 0; k < count; k++) {
@@ -301,6 +309,7 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       d.ma = (const HashMeta*)X.hash_gmeta;
       d.cb = (const uint4*)Y.hash_gcodes;
       d.mb = (const HashMeta*)Y.hash_gmeta;
+      d.offa = X.hash_offsets;
       d.offb = Y.hash_offsets;
       d.da = X.d;
       d.db = Y.d;
@@ -308,20 +317,17 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       sp += (size_t)X.n * SLOT_WORDS;
       d.slots_b = sp;
       sp += (size_t)Y.n * SLOT_WORDS;
-      d.list = lp;
-      d.list_cap = (uint32_t)list_capacity(X.n, Y.n);
-      lp += d.list_cap;
-      d.list_count = counters + k;
+      d.list = lp + (size_t)k * segments * LIST_SEGMENT;
+      d.seg_counts = seg_counts + (size_t)k * segments;
+      d.overflow = overflow_marks + k;
       d.na = X.n;
       d.nb = Y.n;
       d.out_slot = k;
       max_na = std::max(max_na, X.n);
       max_n = std::max(max_n, std::max(X.n, cross_check ? Y.n : 0));
-      // what one pair has to read at the least: the first image's bucket-ordered records (codes and
-      // bucket ids, 32 bytes) and the second image's codes (16 bytes) in all six groups, and one
-      // 16-byte result word per descriptor
-      bytes += GROUPS * ((double)X.n * (sizeof(uint4) + sizeof(HashMeta)) + (double)Y.n * sizeof(uint4)) +
-               16.0 * ((double)X.n + (double)Y.n);
+      // what one pair has to read at the least: both images' bucket-ordered records (code, bucket
+      // ids and index: 32 bytes) in all six groups, and one 16-byte result word per descriptor
+      bytes += GROUPS * ((double)X.n + (double)Y.n) * (sizeof(uint4) + sizeof(HashMeta)) + 16.0 * ((double)X.n + (double)Y.n);
     }
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->profiling) {
@@ -334,16 +340,17 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     const CascadePair* dp = (const CascadePair*)L.cascade_tables.p;
     const int both = cross_check ? 1 : 0;
     if (max_na > 0) {
-      hipLaunchKernelGGL(k_ch_walk<WALK_COUNT>, dim3((unsigned)((max_na + 255) / 256), GROUPS, (unsigned)count), dim3(256), 0,
-                         st, dp, both);
+      hipLaunchKernelGGL(k_ch_walk_count, dim3((unsigned)n_walk, GROUPS, (unsigned)count), dim3(WALK_THREADS), 0, st, dp,
+                         both);
       HIP_TRY(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_ch_nearest, dim3(NEAREST_BLOCKS, 1, (unsigned)count), dim3(256), 0, st, dp, both);
+      hipLaunchKernelGGL(k_ch_nearest, dim3(NEAREST_BLOCKS, 1, (unsigned)count), dim3(256), 0, st, dp, both, (int)segments);
       HIP_TRY(ctx, hipGetLastError());
       // the two kernels below return at once for every pair whose list was complete
       hipLaunchKernelGGL(k_ch_take_all, dim3(FALLBACK_BLOCKS, cross_check ? 2 : 1, (unsigned)count), dim3(256), 0, st, dp,
                          ctx->cascade_counters);
       HIP_TRY(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_ch_walk<WALK_NEAREST>, dim3(FALLBACK_BLOCKS, GROUPS, (unsigned)count), dim3(256), 0, st, dp, both);
+      hipLaunchKernelGGL(k_ch_walk_nearest, dim3(FALLBACK_BLOCKS, GROUPS, (unsigned)count), dim3(WALK_THREADS), 0, st, dp,
+                         both);
       HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_ch_compact, dim3((unsigned)count), dim3(1024), 0, st, dp, both, k_defaults, k_counts, k_lhs, k_rhs,
