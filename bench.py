@@ -95,13 +95,21 @@ def cascade_leg(m, with_cpu, n_images=32, reps=10):
     st = m.cascade_stats()
     m.set_profiling(False)
     gbps = st["match_bytes"] / (st["match_ms"] * 1e-3) / 1e9
+    # HBM-side bytes of one such batch from a separate hardware-counter run of this workload
+    # (tools/collect_cascade_profiles.sh), kept beside the profiles
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "cascade_traffic.json")
+    if os.path.exists(tpath) and n_images == 32:
+        with open(tpath) as fh:
+            traffic = json.load(fh).get("cascade_batch", {}).get("traffic_bytes_per_batch")
     leg = {"matcher": "cascade hash", "value": value, "unit": "pairs/s",
            "workload": "%d synthetic images x %d features with repeated structure, all %d pairs, cross-check"
                        % (n_images, N_FEATURES, len(pairs)),
            "matches": n_matches, "default_records": n_defaults,
            "prepare_seconds_all_images": prepare_s, "list_overflows": st["list_overflows"],
            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                        "traffic": None, "kernel": "one batch, k_ch_walk<COUNT> .. k_ch_compact",
+                        "traffic": traffic, "kernel": "one batch of %d pairs: k_ch_walk_count .. k_ch_compact" % len(pairs),
+                        "bytes_per_batch": st["match_bytes"] / st["match_launches"],
                         "avg_batch_ms": st["match_ms"] / st["match_launches"],
                         "bytes_per_pair": st["match_bytes"] / (reps * len(pairs))}}
     if with_cpu:

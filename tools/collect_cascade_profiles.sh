@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs on the GPU box: the cascade-hash path's throughput line, rocprofv3 kernel statistics of the
+# same command, and the hardware-counter passes.  Results land under gpurun_out/collect_cascade/;
+# copy what is to be kept into profiles/.
+set -o pipefail
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/collect_cascade; rm -rf $OUT; mkdir -p $OUT
+timeout -k 10 300 python -u $R/tools/cascade_bench.py 2>$OUT/bench.err | tee $OUT/cascade_bench.json | cut -c1-400 || exit 1
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/tools/cascade_bench.py --cpu-pairs 0 > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv && cat $OUT/kernel_stats.csv
+ARGS="--cpu-pairs 0 --reps 2"
+run() { local name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc/$name -- python3 $R/tools/cascade_bench.py $ARGS > $OUT/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/pmc_$name.log; return 1; }; }
+run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS &&
+run b GRBM_GUI_ACTIVE GRBM_COUNT SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES SQ_WAVES &&
+run c FETCH_SIZE && run d WRITE_SIZE &&
+python3 $R/tools/pmc_summary.py $OUT/pmc $OUT/traffic.json > $OUT/pmc_summary.txt && grep -A24 "k_ch_walk_count" $OUT/pmc_summary.txt

@@ -35,6 +35,19 @@ def main(root):
             out[engine] = {"kernel": name, "launches_sampled": len(f),
                            "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
                            "fetch_correction": 2.0, "traffic_bytes_per_launch": 2.0 * fetch + write}
+    # The cascade-hash path: one batch = one launch each of the kernels below; their traffic summed.
+    batch = ["k_ch_walk_count", "k_ch_nearest", "k_ch_take_all", "k_ch_walk_nearest", "k_ch_compact"]
+    per = {}
+    for name in acc:
+        short = name.split("::")[-1]
+        if short in batch and "FETCH_SIZE" in acc[name] and "WRITE_SIZE" in acc[name]:
+            f, w = acc[name]["FETCH_SIZE"], acc[name]["WRITE_SIZE"]
+            per[short] = {"launches_sampled": len(f), "FETCH_SIZE_bytes_raw": sum(f) / len(f) * 1024.0,
+                          "WRITE_SIZE_bytes": sum(w) / len(w) * 1024.0}
+            per[short]["traffic_bytes_per_launch"] = 2.0 * per[short]["FETCH_SIZE_bytes_raw"] + per[short]["WRITE_SIZE_bytes"]
+    if per:
+        out["cascade_batch"] = {"kernels": per, "fetch_correction": 2.0,
+                                "traffic_bytes_per_batch": sum(v["traffic_bytes_per_launch"] for v in per.values())}
     if out:
         if len(sys.argv) > 2:
             with open(sys.argv[2], "w") as fh:
