@@ -65,11 +65,14 @@ struct alignas(16) HashMeta {
   uint32_t idx;
 };
 
-// Per-query work space of one pair and direction: 16 words, all zero between batches.
-constexpr int SLOT_WORDS = 16;
-constexpr int SLOT_HIST = 0;       // [0 .. 10] close candidates at Hamming distance h
-constexpr int SLOT_STATE = 12;     // 0: no close candidate seen; 1: seen, but no match; 2 + h: match, bins 0..h taken
-constexpr int SLOT_BEST = 14;      // [14, 15] 64-bit maximum of ~(distance bits << 32 | index): the minimum, inverted
+// Per-query work space of one pair and direction, all zero between batches: a histogram row of 12
+// words (bins 0..10 of close candidates by Hamming distance, one word unused) and, in an array of
+// its own because the compaction reads nothing else, a result of 4 words.
+constexpr int HIST_WORDS = 12;
+constexpr int RES_WORDS = 4;
+constexpr int RES_STATE = 0;       // 0: no close candidate seen; 1: seen, but no match; 2 + h: match, bins 0..h taken
+constexpr int RES_BEST = 2;        // [2, 3] 64-bit maximum of ~(distance bits << 32 | index): the minimum, inverted
+constexpr int SLOT_WORDS = HIST_WORDS + RES_WORDS;   // per query
 constexpr uint32_t STATE_NONE = 1;
 constexpr uint32_t STATE_MATCH = 2;
 
@@ -101,8 +104,10 @@ struct CascadePair {
   const int32_t* offb;
   const float* da;       // descriptor rows
   const float* db;
-  uint32_t* slots_a;     // [na][16]
-  uint32_t* slots_b;     // [nb][16]
+  uint32_t* hist_a;      // [na][12]
+  uint32_t* hist_b;      // [nb][12]
+  uint32_t* res_a;       // [na][4]
+  uint32_t* res_b;       // [nb][4]
   uint2* list;           // close pairs {i, j | h << 28}: one segment of LIST_SEGMENT entries per walk workgroup
   uint32_t* seg_counts;  // entries in each segment; rewritten by every walk
   uint32_t* overflow;    // non-zero: some segment was too small, the list is incomplete (zero between batches)
@@ -354,8 +359,8 @@ __device__ __forceinline__ bool inside_taken_bins(uint32_t state, uint32_t h) { 
 __device__ __forceinline__ void fold_distance(const CascadePair& P, uint32_t i, uint32_t j, bool into_a, bool into_b) {
   const float dist = exact_l2(P.da + (size_t)i * DIM, P.db + (size_t)j * DIM);
   const unsigned long long hi = (unsigned long long)__float_as_uint(dist) << 32;
-  if (into_a) atomicMax(reinterpret_cast<unsigned long long*>(P.slots_a + (size_t)i * SLOT_WORDS + SLOT_BEST), ~(hi | j));
-  if (into_b) atomicMax(reinterpret_cast<unsigned long long*>(P.slots_b + (size_t)j * SLOT_WORDS + SLOT_BEST), ~(hi | i));
+  if (into_a) atomicMax(reinterpret_cast<unsigned long long*>(P.res_a + (size_t)i * RES_WORDS + RES_BEST), ~(hi | j));
+  if (into_b) atomicMax(reinterpret_cast<unsigned long long*>(P.res_b + (size_t)j * RES_WORDS + RES_BEST), ~(hi | i));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,14 +473,14 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
         const uint32_t i = meta.idx, j = other.idx;
         if (MODE == WALK_COUNT) {
 #ifndef SFM_ABLATE_WALK_HIST
-          atomicAdd(P.slots_a + (size_t)i * SLOT_WORDS + SLOT_HIST + h, 1u);
-          if (both_directions) atomicAdd(P.slots_b + (size_t)j * SLOT_WORDS + SLOT_HIST + h, 1u);
+          atomicAdd(P.hist_a + (size_t)i * HIST_WORDS + h, 1u);
+          if (both_directions) atomicAdd(P.hist_b + (size_t)j * HIST_WORDS + h, 1u);
 #endif
           const uint32_t at = atomicAdd(&n_found, 1u);
           if (at < (uint32_t)LIST_SEGMENT) found[at] = make_uint2(i, j | (h << LIST_H_SHIFT));
         } else {
-          const bool fa = inside_taken_bins(P.slots_a[(size_t)i * SLOT_WORDS + SLOT_STATE], h);
-          const bool fb = both_directions && inside_taken_bins(P.slots_b[(size_t)j * SLOT_WORDS + SLOT_STATE], h);
+          const bool fa = inside_taken_bins(P.res_a[(size_t)i * RES_WORDS + RES_STATE], h);
+          const bool fb = both_directions && inside_taken_bins(P.res_b[(size_t)j * RES_WORDS + RES_STATE], h);
           if (fa || fb) fold_distance(P, i, j, fa, fb);
         }
       }
@@ -564,14 +569,12 @@ __global__ __launch_bounds__(256) void k_ch_nearest(const CascadePair* __restric
     }
     const uint2 entry = P.list[(size_t)lo * LIST_SEGMENT + (k - start[lo])];
     const uint32_t i = entry.x, j = entry.y & ((1u << LIST_H_SHIFT) - 1u), h = entry.y >> LIST_H_SHIFT;
-    uint32_t* sa = P.slots_a + (size_t)i * SLOT_WORDS;
-    const uint32_t state_a = take_state(sa);
-    sa[SLOT_STATE] = state_a;
+    const uint32_t state_a = take_state(P.hist_a + (size_t)i * HIST_WORDS);
+    P.res_a[(size_t)i * RES_WORDS + RES_STATE] = state_a;
     bool fb = false;
     if (both_directions) {
-      uint32_t* sb = P.slots_b + (size_t)j * SLOT_WORDS;
-      const uint32_t state_b = take_state(sb);
-      sb[SLOT_STATE] = state_b;
+      const uint32_t state_b = take_state(P.hist_b + (size_t)j * HIST_WORDS);
+      P.res_b[(size_t)j * RES_WORDS + RES_STATE] = state_b;
       fb = inside_taken_bins(state_b, h);
     }
     const bool fa = inside_taken_bins(state_a, h);
@@ -587,14 +590,15 @@ __global__ __launch_bounds__(256) void k_ch_take_all(const CascadePair* __restri
   if (*P.overflow == 0) return;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(overflowed_pairs, 1ull);
   const int n = blockIdx.y == 0 ? P.na : P.nb;
-  uint32_t* slots = blockIdx.y == 0 ? P.slots_a : P.slots_b;
+  uint32_t* hist = blockIdx.y == 0 ? P.hist_a : P.hist_b;
+  uint32_t* res = blockIdx.y == 0 ? P.res_a : P.res_b;
   for (int q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
-    uint32_t* slot = slots + (size_t)q * SLOT_WORDS;
+    uint32_t* slot = hist + (size_t)q * HIST_WORDS;
     const uint4 h0 = reinterpret_cast<const uint4*>(slot)[0];
     const uint4 h1 = reinterpret_cast<const uint4*>(slot)[1];
     const uint4 h2 = reinterpret_cast<const uint4*>(slot)[2];
     const uint32_t any = h0.x | h0.y | h0.z | h0.w | h1.x | h1.y | h1.z | h1.w | h2.x | h2.y | h2.z;
-    if (any) slot[SLOT_STATE] = take_state(slot);
+    if (any) res[(size_t)q * RES_WORDS + RES_STATE] = take_state(slot);
   }
 }
 
@@ -603,10 +607,11 @@ __global__ __launch_bounds__(256) void k_ch_take_all(const CascadePair* __restri
 // lhs index.  out_defaults: the records `Matches temp(matches.size())` holds before the survivors
 // are appended (.cc:187) -- one per forward match, cross-check only.  Every slot that was touched
 // goes back to zero, and so does the list's overflow mark.
-__device__ __forceinline__ void clear_slot(uint32_t* slot) {
+__device__ __forceinline__ void clear_query(uint32_t* hist_row, uint32_t* res) {
   const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-  for (int w = 0; w < SLOT_WORDS / 4; w++) reinterpret_cast<uint4*>(slot)[w] = z;
+  for (int w = 0; w < HIST_WORDS / 4; w++) reinterpret_cast<uint4*>(hist_row)[w] = z;
+  *reinterpret_cast<uint4*>(res) = z;
 }
 
 __global__ __launch_bounds__(1024) void k_ch_compact(const CascadePair* __restrict__ pairs, int cross_check,
@@ -637,16 +642,16 @@ __global__ __launch_bounds__(1024) void k_ch_compact(const CascadePair* __restri
       j[k] = 0;
       d[k] = 0.0f;
       if (i < P.na) {
-        uint32_t* sa = P.slots_a + (size_t)i * SLOT_WORDS;
-        const uint4 t = reinterpret_cast<const uint4*>(sa)[3];   // state, -, best (inverted) low, high
-        if (t.x != 0) clear_slot(sa);                            // only this thread ever reads slot i
+        uint32_t* ra = P.res_a + (size_t)i * RES_WORDS;
+        const uint4 t = *reinterpret_cast<const uint4*>(ra);     // state, -, best (inverted) low, high
+        if (t.x != 0) clear_query(P.hist_a + (size_t)i * HIST_WORDS, ra);   // only this thread ever reads query i
         if (t.x >= STATE_MATCH) {
           nfwd++;
           j[k] = (int)~t.z;
           d[k] = __uint_as_float(~t.w);
           keep[k] = true;
           if (cross_check) {
-            const uint4 u = reinterpret_cast<const uint4*>(P.slots_b + (size_t)j[k] * SLOT_WORDS)[3];
+            const uint4 u = *reinterpret_cast<const uint4*>(P.res_b + (size_t)j[k] * RES_WORDS);
             keep[k] = u.x >= STATE_MATCH && (int)~u.z == i;
           }
         }
@@ -695,8 +700,8 @@ __global__ __launch_bounds__(1024) void k_ch_compact(const CascadePair* __restri
   // the second image's slots were read by any thread above: cleared only now
   if (cross_check) {
     for (int q = tid; q < P.nb; q += 1024) {
-      uint32_t* sb = P.slots_b + (size_t)q * SLOT_WORDS;
-      if (sb[SLOT_STATE] != 0) clear_slot(sb);
+      uint32_t* rb = P.res_b + (size_t)q * RES_WORDS;
+      if (rb[RES_STATE] != 0) clear_query(P.hist_b + (size_t)q * HIST_WORDS, rb);
     }
   }
   if (tid == 0) {

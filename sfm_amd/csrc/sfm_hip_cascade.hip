@@ -313,10 +313,14 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       d.offb = Y.hash_offsets;
       d.da = X.d;
       d.db = Y.d;
-      d.slots_a = sp;
-      sp += (size_t)X.n * SLOT_WORDS;
-      d.slots_b = sp;
-      sp += (size_t)Y.n * SLOT_WORDS;
+      d.hist_a = sp;
+      sp += (size_t)X.n * HIST_WORDS;
+      d.hist_b = sp;
+      sp += (size_t)Y.n * HIST_WORDS;
+      d.res_a = sp;
+      sp += (size_t)X.n * RES_WORDS;
+      d.res_b = sp;
+      sp += (size_t)Y.n * RES_WORDS;
       d.list = lp + (size_t)k * segments * LIST_SEGMENT;
       d.seg_counts = seg_counts + (size_t)k * segments;
       d.overflow = overflow_marks + k;
