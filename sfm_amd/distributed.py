@@ -45,6 +45,31 @@ def match_pairs_sharded(matcher, pairs, ratio=0.8, cross_check=True, rank=0, wor
     return out
 
 
+def cascade_match_pairs_sharded(matcher, pairs, cross_check=True, rank=0, world=1, group=None):
+    """The cascade-hash matcher over ranks.  Hashing depends on the mean vector of ALL images the
+    job's pair list names (cascade_hash_matcher.cc:148-165), so every rank prepares with the whole
+    list (matcher.cascade_prepare(pairs): every rank holds every image, as above) and only the
+    matching itself is sliced.  matcher: anything with cascade_prepare(pairs) and
+    cascade_match_pairs(pairs, cross_check).  Returns the full, ordered list of
+    (n_default, lhs, rhs, dist) on rank 0 and None elsewhere."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    matcher.cascade_prepare(pairs)
+    lo, hi = shard_bounds(len(pairs), rank, world)
+    local = matcher.cascade_match_pairs(pairs[lo:hi], cross_check) if hi > lo else []
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((lo, local), gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = []
+    for lo_r, res in sorted(gathered, key=lambda t: t[0]):
+        assert lo_r == len(out), "shards do not tile the pair list"
+        out.extend(res)
+    return out
+
+
 def replicate_images(matcher, images, rank=0, world=1, group=None, device=None, method="collective"):
     """Give every rank's matcher every image.
 

@@ -112,3 +112,51 @@ def test_replication_collective_two_ranks_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("REPLICATE_OK" in o for o in outs)
+
+
+CASCADE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+from sfm_amd import synth
+from sfm_amd.distributed import exhaustive_pairs, cascade_match_pairs_sharded
+from oracle import cascade
+
+class OracleCascade:            # stands in for the GPU context: same calls, CPU arithmetic
+    def __init__(self, images): self.images, self.mean = images, None
+    def cascade_prepare(self, pairs):
+        self.mean = cascade.mean([self.images[int(i)] for i in cascade.image_order(pairs)])
+    def cascade_match_pairs(self, pairs, cross):
+        return [cascade.match_pair(self.images[int(a)], self.images[int(b)], self.mean, cross) for a, b in pairs]
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+imgs = synth.make_repetitive_set(4, 300, 0.6, 2, seed=23, sigma=0.002)
+images = {10 + i: im[:n] for i, (im, n) in enumerate(zip(imgs, (300, 200, 0, 300)))}
+pairs = exhaustive_pairs(images.keys())
+got = cascade_match_pairs_sharded(OracleCascade(images), pairs, True, rank, world)
+if rank == 0:
+    whole, _, _ = cascade.match_set(images, pairs, True)     # the job on one process
+    assert len(got) == len(pairs) == 6
+    for (a, b), (nd, l, r, d) in zip(pairs.tolist(), got):
+        wnd, wl, wr = whole[(a, b)]
+        assert (nd, l.tolist(), r.tolist()) == (wnd, wl.tolist(), wr.tolist())
+    print("CASCADE_SHARDING_OK", sum(len(g[1]) for g in got))
+else:
+    assert got is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_cascade_two_ranks_over_gloo(tmp_path):
+    """The mean vector comes from the whole job's images on every rank, whatever slice it matches."""
+    script = tmp_path / "worker.py"
+    script.write_text(CASCADE_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "CASCADE_SHARDING_OK" in outs[0]
