@@ -186,3 +186,46 @@ def test_errors(matcher):
     matcher.upload(1, d)       # a new upload discards the image's hashes
     with pytest.raises(binding.SfmHipError, match="not been hashed"):
         matcher.cascade_match_pairs([(0, 1)])
+
+
+def test_many_pairs_split_into_batches_and_pageable_outputs(matcher):
+    """More pairs than one launch takes (1024), results into ordinary (pageable) host arrays."""
+    import ctypes
+    imgs = synth.make_repetitive_set(48, 256, 0.7, 2, seed=14, sigma=0.002)
+    images = {i: d[: 256 - (i % 5)] for i, d in enumerate(imgs)}
+    ids = sorted(images)
+    pairs = [(a, b) for x, a in enumerate(ids) for b in ids[x + 1:]]
+    assert len(pairs) == 1128
+    _upload(matcher, images)
+    mean = matcher.cascade_prepare(pairs)
+    p = np.ascontiguousarray(pairs, np.int64)
+    stride = 256
+    dfl = np.full(len(pairs), -7, np.int32)
+    cnt = np.full(len(pairs), -7, np.int32)
+    lhs = np.full((len(pairs), stride), -7, np.int32)
+    rhs = np.full((len(pairs), stride), -7, np.int32)
+    dist = np.zeros((len(pairs), stride), np.float32)
+    lib = binding.library()
+    rc = lib.sfm_hip_cascade_match_pairs(matcher._h, p.ctypes.data, len(pairs), 1, dfl.ctypes.data, cnt.ctypes.data,
+                                         lhs.ctypes.data, rhs.ctypes.data, dist.ctypes.data, stride)
+    assert rc == 0
+    matcher.sync()
+    total = 0
+    for k, (a, b) in enumerate(pairs):
+        end, el, er, ed = cascade.match_pair(images[a], images[b], mean, True)
+        c = int(cnt[k])
+        assert (int(dfl[k]), lhs[k, :c].tolist(), rhs[k, :c].tolist()) == (end, el.tolist(), er.tolist()), (a, b)
+        assert dist[k, :c].view(np.uint32).tolist() == ed.view(np.uint32).tolist()
+        total += c
+    assert total > 1000
+    assert matcher.cascade_stats()["workspace_dirty_words"] == 0
+
+
+def test_large_and_unequal_images(matcher):
+    a, b = synth.make_repetitive_set(2, 20000, 0.4, 2, seed=15, sigma=0.002)
+    images = {0: a, 1: b[:7001], 2: a[:300]}
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    _upload(matcher, images)
+    matcher.cascade_prepare(pairs)
+    assert _check_pairs(matcher, images, pairs, True) > 50
+    assert _check_pairs(matcher, images, [(1, 0), (2, 0)], False) > 50    # first image the smaller one
