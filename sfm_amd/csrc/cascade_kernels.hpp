@@ -139,43 +139,23 @@ __global__ __launch_bounds__(128) void k_ch_colsum(const ImageRef* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Hashing (cascade_hash_matcher.cc:18-38).  One lane per descriptor: the centred descriptor stays
-// in registers, the projection rows arrive through scalar loads (they are the same for every
-// lane), each projection is the sum over j = 0..127 of row[j] * d[j] in that order, product and
-// sum rounded separately.
-// proj holds the 188 rows (128 primary, then 6 x 10 secondary) in blocks of four, a block stored
-// as [j][4] so that one scalar load brings four rows' entries for four consecutive j, followed by
-// the 128-float mean: proj[(b * 128 + j) * 4 + k] = row 4b + k, entry j.
+// Hashing (cascade_hash_matcher.cc:18-38).  A workgroup takes 64 descriptors, one per lane; its
+// four wavefronts each compute 48 of the 188 (padded to 192) projections of those descriptors, so a
+// wavefront needs few registers and eight of them share a SIMD, which is what hides the latency
+// of the scalar loads the projection rows arrive through (they are the same for every lane).
+// Each projection is the sum over j = 0..127 of row[j] * d[j] in that order, product and sum
+// rounded separately.
+// proj holds the rows transposed and padded, proj[j * 192 + r] = row r, entry j (rows 0..127
+// primary, 128..187 the 6 x 10 secondary, 188..191 zero), followed by the 128-float mean.
 // ---------------------------------------------------------------------------------------------
-constexpr int PROJ_BLOCK = 4;
-constexpr int PROJ_BLOCKS = NPROJ / PROJ_BLOCK;   // 47
-static_assert(NPROJ % PROJ_BLOCK == 0, "projection rows come in blocks of four");
+constexpr int PROJ_PADDED = 192;
+constexpr int PROJ_PER_WAVE = PROJ_PADDED / 4;    // 48
+constexpr int PROJ_MEAN_AT = DIM * PROJ_PADDED;   // where the mean starts
 
-__device__ __forceinline__ uint32_t project_block(const float* __restrict__ blk, const float (&d)[DIM]) {
+__global__ __launch_bounds__(256) void k_ch_hash(const HashJob* __restrict__ jobs, int n_jobs,
+                                                 const float* __restrict__ proj) {
 #pragma clang fp contract(off)
-  float acc[PROJ_BLOCK] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int j0 = 0; j0 < DIM; j0 += 4) {
-    float4 p[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) p[j] = *reinterpret_cast<const float4*>(blk + (j0 + j) * PROJ_BLOCK);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      acc[0] = acc[0] + p[j].x * d[j0 + j];
-      acc[1] = acc[1] + p[j].y * d[j0 + j];
-      acc[2] = acc[2] + p[j].z * d[j0 + j];
-      acc[3] = acc[3] + p[j].w * d[j0 + j];
-    }
-    // keeps the compiler from issuing all scalar loads of a block up front, which would need
-    // more scalar registers than there are
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return (acc[0] > 0.0f ? 1u : 0u) | (acc[1] > 0.0f ? 2u : 0u) | (acc[2] > 0.0f ? 4u : 0u) | (acc[3] > 0.0f ? 8u : 0u);
-}
-
-__global__ __launch_bounds__(64) void k_ch_hash(const HashJob* __restrict__ jobs, int n_jobs,
-                                                const float* __restrict__ proj) {
-#pragma clang fp contract(off)
+  __shared__ unsigned long long signs[4][64];
   // which job this workgroup belongs to: the last one whose first_block is not beyond it
   int lo = 0, hi = n_jobs - 1;
   while (lo < hi) {
@@ -184,32 +164,42 @@ __global__ __launch_bounds__(64) void k_ch_hash(const HashJob* __restrict__ jobs
     else hi = mid - 1;
   }
   const HashJob job = jobs[lo];
-  const int row = ((int)blockIdx.x - job.first_block) * 64 + (int)threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = ((int)blockIdx.x - job.first_block) * 64 + lane;
   const bool live = row < job.n;
-  const float* mean = proj + NPROJ * DIM;
-  float d[DIM];
-  {
-    const float4* src = reinterpret_cast<const float4*>(job.d + (size_t)(live ? row : 0) * DIM);
+  const float* mean = proj + PROJ_MEAN_AT;
+  const float4* src = reinterpret_cast<const float4*>(job.d + (size_t)(live ? row : 0) * DIM);
+  const float* rows = proj + wv * PROJ_PER_WAVE;
+  float acc[PROJ_PER_WAVE];
 #pragma unroll
-    for (int j = 0; j < DIM / 4; j++) {
-      const float4 v = src[j];
-      d[4 * j + 0] = v.x - mean[4 * j + 0];     // cascade_hash_matcher.cc:21
-      d[4 * j + 1] = v.y - mean[4 * j + 1];
-      d[4 * j + 2] = v.z - mean[4 * j + 2];
-      d[4 * j + 3] = v.w - mean[4 * j + 3];
+  for (int k = 0; k < PROJ_PER_WAVE; k++) acc[k] = 0.0f;
+#pragma unroll 1
+  for (int j0 = 0; j0 < DIM; j0 += 4) {
+    const float4 v = src[j0 >> 2];
+    const float d[4] = {v.x - mean[j0], v.y - mean[j0 + 1], v.z - mean[j0 + 2], v.w - mean[j0 + 3]};   // .cc:21
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float* p = rows + (size_t)(j0 + j) * PROJ_PADDED;
+#pragma unroll
+      for (int k = 0; k < PROJ_PER_WAVE; k++) acc[k] = acc[k] + p[k] * d[j];
     }
   }
-  // sign bits of the 188 projections, row r at bit r % 32 of word r / 32
-  uint32_t word[6];
+  unsigned long long bits = 0;
 #pragma unroll
-  for (int w = 0; w < 6; w++) {
-    uint32_t bits = 0;
-    const int nb = w < 5 ? 8 : PROJ_BLOCKS - 40;
-#pragma unroll 1
-    for (int kb = 0; kb < nb; kb++)
-      bits |= project_block(proj + (size_t)(w * 8 + kb) * DIM * PROJ_BLOCK, d) << (kb * 4);
-    word[w] = bits;
-  }
+  for (int k = 0; k < PROJ_PER_WAVE; k++) bits |= (unsigned long long)(acc[k] > 0.0f ? 1 : 0) << k;
+  signs[wv][lane] = bits;
+  __syncthreads();
+  if (wv != 0 || !live) return;
+  // sign bits of the 192 projections, row r at bit r % 32 of word r / 32
+  const unsigned long long s0 = signs[0][lane], s1 = signs[1][lane], s2 = signs[2][lane], s3 = signs[3][lane];
+  uint32_t word[6];
+  word[0] = (uint32_t)s0;                                     // rows   0.. 31
+  word[1] = (uint32_t)(s0 >> 32) | (uint32_t)(s1 << 16);      // rows  32.. 63 = s0[32..47], s1[0..15]
+  word[2] = (uint32_t)(s1 >> 16);                             // rows  64.. 95 = s1[16..47]
+  word[3] = (uint32_t)s2;                                     // rows  96..127 = s2[0..31]
+  word[4] = (uint32_t)(s2 >> 32) | (uint32_t)(s3 << 16);      // rows 128..159 = s2[32..47], s3[0..15]
+  word[5] = (uint32_t)(s3 >> 16);                             // rows 160..191 = s3[16..47]
   HashRec rec;
 #pragma unroll
   for (int w = 0; w < 4; w++) rec.code[w] = word[w];                // .cc:24-26
@@ -223,7 +213,7 @@ __global__ __launch_bounds__(64) void k_ch_hash(const HashJob* __restrict__ jobs
   rec.bids[1] = bid[2] | (bid[3] << 16);
   rec.bids[2] = bid[4] | (bid[5] << 16);
   rec.idx = (uint32_t)row;
-  if (live) job.recs[row] = rec;
+  job.recs[row] = rec;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ using namespace sfm_host;
 
 namespace {
 
-constexpr size_t PROJ_FLOATS = (size_t)(NPROJ + 1) * DIM;   // projection rows, then the mean
+constexpr size_t PROJ_FLOATS = (size_t)PROJ_MEAN_AT + DIM;   // projection rows (transposed, padded), then the mean
 constexpr int MAX_PAIRS_PER_BATCH = 1024;
 constexpr size_t SLOT_BYTES_PER_BATCH = (size_t)2 << 30;
 constexpr size_t LIST_BYTES_PER_BATCH = (size_t)1 << 30;
@@ -79,11 +79,11 @@ int sfm_hip_cascade_set_projection(sfm_hip_ctx* ctx, const float* primary, const
   if (!primary || !secondary) return fail(ctx, SFM_HIP_ERR_INVALID, "null projection matrix");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (!ctx->cascade_projection) HIP_TRY(ctx, hipMalloc((void**)&ctx->cascade_projection, PROJ_FLOATS * sizeof(float)));
-  // device layout: blocks of four rows stored [j][4] (see k_ch_hash)
-  std::vector<float> t((size_t)NPROJ * DIM);
+  // device layout: transposed and padded to 192 rows, [j][192] (see k_ch_hash)
+  std::vector<float> t((size_t)PROJ_MEAN_AT, 0.0f);
   for (int r = 0; r < NPROJ; r++) {
     const float* row = r < CODE_BITS ? primary + (size_t)r * DIM : secondary + (size_t)(r - CODE_BITS) * DIM;
-    for (int j = 0; j < DIM; j++) t[((size_t)(r / PROJ_BLOCK) * DIM + j) * PROJ_BLOCK + r % PROJ_BLOCK] = row[j];
+    for (int j = 0; j < DIM; j++) t[(size_t)j * PROJ_PADDED + r] = row[j];
   }
   if (int rc = sync_all(ctx)) return rc;
   HIP_TRY(ctx, hipMemcpy(ctx->cascade_projection, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -132,7 +132,7 @@ int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
   if (rehash)
     if (int rc = sync_all(ctx)) return rc;
   hipStream_t st = ctx->upload_stream;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->cascade_projection + (size_t)NPROJ * DIM, mean128, DIM * sizeof(float),
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->cascade_projection + (size_t)PROJ_MEAN_AT, mean128, DIM * sizeof(float),
                               hipMemcpyHostToDevice, st));
   std::vector<HashJob> jobs;
   int blocks = 0;
@@ -169,7 +169,7 @@ int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
   HIP_TRY(ctx, hipMalloc(&table.p, jobs.size() * sizeof(HashJob)));
   HIP_TRY(ctx, hipMemcpyAsync(table.p, jobs.data(), jobs.size() * sizeof(HashJob), hipMemcpyHostToDevice, st));
   if (blocks > 0) {
-    hipLaunchKernelGGL(k_ch_hash, dim3((unsigned)blocks), dim3(64), 0, st, (const HashJob*)table.p, (int)jobs.size(),
+    hipLaunchKernelGGL(k_ch_hash, dim3((unsigned)blocks), dim3(256), 0, st, (const HashJob*)table.p, (int)jobs.size(),
                        (const float*)ctx->cascade_projection);
     HIP_TRY(ctx, hipGetLastError());
   }
