@@ -240,6 +240,30 @@ int sfm_hip_cascade_prepare(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n
 int sfm_hip_cascade_get_stats(sfm_hip_ctx* ctx, sfm_hip_cascade_stats* out);
 int sfm_hip_cascade_reset_stats(sfm_hip_ctx* ctx);
 
+/* ------------------------------------------------------------------------------------------
+ * Geometric verification of matches: the GPU side of ComputeFundamentalMatrix
+ * (src/sfm_main.cc:17-50) as GeometryFilter (src/sfm_main.cc:259-282) calls it once per image pair,
+ * i.e. Ransac<EightPointFundamentalSolverImpl, EpipolarLineError>::Inference (src/ransac.hpp:94-150,
+ * src/solver/fundamental_solver.cc:13-86, src/solver/fundamental_solver.hpp:59-78) followed by the
+ * classification of every match under the model found (sfm_main.cc:32-42).
+ *
+ * Pair p owns the matches [match_offsets[p], match_offsets[p + 1]); lhs_xy / rhs_xy hold their pixel
+ * positions in the first / second image, two doubles per match (the observations of the reference's
+ * Match records).  Outputs, host memory: out_F 9 doubles per pair, row-major, the model RANSAC ended
+ * with (zeros for a pair with fewer than eight matches, which the reference cannot sample);
+ * out_inlier_flags one byte per match, 1 where the epipolar-line error under that model is below
+ * 3.84; out_inlier_counts their number per pair -- ComputeFundamentalMatrix returns true when it
+ * exceeds 30 (sfm_main.cc:44); out_rounds (may be NULL) the RANSAC rounds run.
+ *
+ * The reference seeds its sampler from std::random_device in every round, so its result differs from
+ * run to run; here round r of pair p reads a counter-based random stream keyed by
+ * (seed, first_pair_index + p, r), which makes a run repeatable and a pair's result independent of
+ * how the pair list is cut into calls.  The singular vectors the reference takes from its matrix
+ * library's SVD come from a Jacobi eigen-solver; all arithmetic is fp64.  Blocking. */
+int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64_t* match_offsets, const double* lhs_xy,
+                                  const double* rhs_xy, uint64_t seed, int64_t first_pair_index, double* out_F,
+                                  uint8_t* out_inlier_flags, int32_t* out_inlier_counts, int32_t* out_rounds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ EXPORTS = (
     "sfm_hip_cascade_set_projection", "sfm_hip_cascade_column_sums", "sfm_hip_cascade_hash_images",
     "sfm_hip_cascade_get_hashes", "sfm_hip_cascade_match_pairs", "sfm_hip_cascade_reference_projection",
     "sfm_hip_cascade_image_order", "sfm_hip_cascade_prepare", "sfm_hip_cascade_get_stats",
-    "sfm_hip_cascade_reset_stats",
+    "sfm_hip_cascade_reset_stats", "sfm_hip_geometry_verify_pairs",
 )
 
 CASCADE_GROUPS, CASCADE_GROUP_BITS, CASCADE_CODE_BITS = 6, 10, 128
@@ -94,6 +94,7 @@ def library():
     lib.sfm_hip_cascade_prepare.argtypes = [vp, vp, i32, vp]
     lib.sfm_hip_cascade_get_stats.argtypes = [vp, ctypes.POINTER(CascadeStats)]
     lib.sfm_hip_cascade_reset_stats.argtypes = [vp]
+    lib.sfm_hip_geometry_verify_pairs.argtypes = [vp, i32, vp, vp, vp, ctypes.c_uint64, i64, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -326,6 +327,29 @@ class Matcher:
 
     def cascade_reset_stats(self):
         self._check(self._lib.sfm_hip_cascade_reset_stats(self._h), "sfm_hip_cascade_reset_stats")
+
+    # ---- geometric verification -----------------------------------------------------------
+    def geometry_verify_pairs(self, matches, seed=0, first_pair_index=0):
+        """matches: [(lhs_xy [n, 2], rhs_xy [n, 2])] per pair.  Returns per pair
+        (ok, F [3, 3], inlier flags uint8 [n], rounds) as ComputeFundamentalMatrix decides them."""
+        sizes = [len(l) for l, _ in matches]
+        offsets = np.zeros(len(matches) + 1, np.int64)
+        offsets[1:] = np.cumsum(sizes)
+        total = int(offsets[-1])
+        lhs = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float64).reshape(-1, 2) for l, _ in matches] or
+                                                  [np.zeros((0, 2))]), dtype=np.float64)
+        rhs = np.ascontiguousarray(np.concatenate([np.asarray(r, np.float64).reshape(-1, 2) for _, r in matches] or
+                                                  [np.zeros((0, 2))]), dtype=np.float64)
+        F = np.zeros((len(matches), 9), np.float64)
+        flags = np.zeros(max(total, 1), np.uint8)
+        counts = np.zeros(max(len(matches), 1), np.int32)
+        rounds = np.zeros(max(len(matches), 1), np.int32)
+        self._check(self._lib.sfm_hip_geometry_verify_pairs(self._h, len(matches), offsets.ctypes.data, lhs.ctypes.data,
+                                                            rhs.ctypes.data, int(seed), int(first_pair_index),
+                                                            F.ctypes.data, flags.ctypes.data, counts.ctypes.data,
+                                                            rounds.ctypes.data), "sfm_hip_geometry_verify_pairs")
+        return [(int(counts[k]) > 30, F[k].reshape(3, 3).copy(), flags[offsets[k]:offsets[k + 1]].copy(), int(rounds[k]))
+                for k in range(len(matches))]
 
     def set_engine(self, name):
         """'f32' (fp32 matrix instructions) or 'f16x3' (split fp16 products): include/sfm_hip.h."""

@@ -40,7 +40,8 @@ def build_library(force=False):
     """libsfm_hip.so: HIP kernels + C ABI (include/sfm_hip.h)."""
     os.makedirs(LIBDIR, exist_ok=True)
     shared = [os.path.join(CSRC, "ctx.hpp"), os.path.join(ROOT, "include", "sfm_hip.h")]
-    units = {"sfm_hip_capi.hip": ["bf_kernels.hpp"], "sfm_hip_cascade.hip": ["cascade_kernels.hpp"]}
+    units = {"sfm_hip_capi.hip": ["bf_kernels.hpp"], "sfm_hip_cascade.hip": ["cascade_kernels.hpp"],
+             "sfm_hip_geometry.hip": ["geometry_kernels.hpp"]}
     objs = []
     for unit, headers in units.items():
         src = os.path.join(CSRC, unit)

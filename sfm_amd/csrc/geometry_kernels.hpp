@@ -1,0 +1,313 @@
+// gfx950 kernels of the geometric verification of matches: per image pair a fundamental matrix by
+// RANSAC over the eight-point fit, and the matches that agree with it.  The GPU side of the
+// reference's ComputeFundamentalMatrix (src/sfm_main.cc:17-50), i.e. Ransac<...>::Inference
+// (src/ransac.hpp:94-150) over EightPointFundamentalSolverImpl::Fit
+// (src/solver/fundamental_solver.cc:13-86) with EpipolarLineError (src/solver/fundamental_solver.hpp:59-78).
+//
+// The reference runs its rounds one after the other because the number of rounds shrinks as better
+// models turn up.  Here a launch evaluates 256 rounds of every unfinished pair at once (one thread per
+// round: sample, fit, count), then one thread per pair replays the reference's bookkeeping over those
+// 256 results in round order -- which yields exactly what the sequential loop would, the rounds
+// past the stopping point being wasted work -- and the host launches again while any pair is unfinished.
+//
+// Arithmetic is fp64, every sum left to right with unfused multiply and add.  The singular vectors
+// the reference takes from Eigen's JacobiSVD come from a cyclic Jacobi eigen-solver of the symmetric
+// matrices A^T A and F^T F with a fixed number of sweeps, fully unrolled so that both matrices stay
+// in registers.  The reference draws its samples from a std::mt19937 it seeds from
+// std::random_device for every round; here the same selection-sampling algorithm (ransac.hpp:34-59)
+// reads a counter-based stream keyed by (seed, pair, round), so a run can be repeated.
+#ifndef SFM_AMD_CSRC_GEOMETRY_KERNELS_HPP_
+#define SFM_AMD_CSRC_GEOMETRY_KERNELS_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sfm_geometry {
+
+constexpr int SAMPLE = 8;                 // MINIMUM_DATA_POINT, fundamental_solver.hpp:21
+constexpr uint32_t MAX_ROUNDS = 4096;     // MaxEpoch, ransac.hpp:97
+constexpr int ROUNDS_PER_LAUNCH = 256;
+constexpr int HYP_THREADS = 64;           // one wavefront: the fit needs most of the register file
+constexpr int SWEEPS9 = 12, SWEEPS3 = 8;
+
+struct GeoState {
+  double best_F[9];
+  uint32_t rounds_limit;    // N of ransac.hpp:98, only ever lowered
+  uint32_t rounds_done;     // sample_count
+  uint32_t best_count;      // inliers of the best model so far
+  uint32_t done;
+};
+
+struct GeoPair {
+  const double* lhs;               // [n][2] pixel positions in the first image
+  const double* rhs;               // [n][2] in the second
+  const uint32_t* rounds_needed;   // [n + 1]: ransac.hpp:128-131 as a function of the inlier count
+  GeoState* state;
+  double* hyp_F;                   // [256][9] models of the current launch
+  uint32_t* hyp_count;             // [256] their inlier counts
+  uint8_t* flags;                  // [n] final classification
+  uint32_t* n_inliers;
+  int32_t n;
+  int32_t pad_;
+  uint64_t stream;                 // key of this pair's random stream
+};
+
+// ---- random numbers: integer arithmetic only, the same bits on every machine ------------------
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline uint64_t pair_stream(uint64_t seed, uint64_t pair) {
+  return mix64(mix64(seed ^ 0xD1B54A32D192ED03ull) + pair * 0x9E3779B97F4A7C15ull);
+}
+__device__ __forceinline__ uint64_t round_key(uint64_t stream, uint64_t round) { return stream ^ mix64(round + 0x632BE59BD9B4E019ull); }
+__device__ __forceinline__ uint64_t stream_word(uint64_t key, uint64_t j) { return mix64(key + (j + 1) * 0x9E3779B97F4A7C15ull); }
+
+// ---- the fit ----------------------------------------------------------------------------------
+// One Jacobi rotation of the symmetric matrix S (upper triangle) in the (P, Q) plane, applied to
+// the eigenvector matrix V as well.  Everything is indexed by compile-time constants.
+template <int N, int P, int Q>
+__device__ __forceinline__ void rotate_pq(double (&S)[N][N], double (&V)[N][N]) {
+#pragma clang fp contract(off)
+  const double apq = S[P][Q];
+  if (apq == 0.0) return;
+  const double theta = (S[Q][Q] - S[P][P]) / (2.0 * apq);
+  double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+  if (theta < 0.0) t = -t;
+  const double c = 1.0 / sqrt(t * t + 1.0);
+  const double s = t * c;
+  const double tau = s / (1.0 + c);
+  const double h = t * apq;
+  S[P][P] = S[P][P] - h;
+  S[Q][Q] = S[Q][Q] + h;
+  S[P][Q] = 0.0;
+#define SFM_GEO_ROTATE(x, y)                \
+  {                                         \
+    const double g_ = (x), k_ = (y);        \
+    (x) = g_ - s * (k_ + g_ * tau);         \
+    (y) = k_ + s * (g_ - k_ * tau);         \
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    if (k < P) SFM_GEO_ROTATE(S[k][P], S[k][Q])
+    else if (k > P && k < Q) SFM_GEO_ROTATE(S[P][k], S[k][Q])
+    else if (k > Q) SFM_GEO_ROTATE(S[P][k], S[Q][k])
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) SFM_GEO_ROTATE(V[k][P], V[k][Q])
+#undef SFM_GEO_ROTATE
+}
+
+template <int N, int P, int Q>
+__device__ __forceinline__ void sweep_from(double (&S)[N][N], double (&V)[N][N]) {
+  rotate_pq<N, P, Q>(S, V);
+  if constexpr (Q + 1 < N) sweep_from<N, P, Q + 1>(S, V);
+  else if constexpr (P + 2 < N) sweep_from<N, P + 1, P + 2>(S, V);
+}
+
+// Cyclic Jacobi: S becomes (nearly) diagonal, V its eigenvectors; returns the column of V that
+// belongs to the diagonal entry of smallest magnitude in `out`.
+template <int N>
+__device__ __forceinline__ void smallest_eigenvector(double (&S)[N][N], int sweeps, double (&out)[N]) {
+  double V[N][N];
+#pragma unroll
+  for (int a = 0; a < N; a++)
+#pragma unroll
+    for (int b = 0; b < N; b++) V[a][b] = a == b ? 1.0 : 0.0;
+#pragma unroll 1
+  for (int sw = 0; sw < sweeps; sw++) sweep_from<N, 0, 1>(S, V);
+  int at = 0;
+  double least = fabs(S[0][0]);
+#pragma unroll
+  for (int a = 1; a < N; a++) {
+    const double m = fabs(S[a][a]);
+    if (m < least) {
+      least = m;
+      at = a;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double v = V[k][0];
+#pragma unroll
+    for (int a = 1; a < N; a++) v = at == a ? V[k][a] : v;
+    out[k] = v;
+  }
+}
+
+// fundamental_solver.cc:13-53 for eight points (x, y, x', y'); F row-major
+__device__ __forceinline__ void fit_eight(const double (&px)[SAMPLE], const double (&py)[SAMPLE], const double (&qx)[SAMPLE],
+                                          const double (&qy)[SAMPLE], double (&F)[9]) {
+#pragma clang fp contract(off)
+  double S[9][9];
+  {
+    double A[SAMPLE][9];
+#pragma unroll
+    for (int i = 0; i < SAMPLE; i++) {   // fundamental_solver.cc:25-27
+      A[i][0] = qx[i] * px[i]; A[i][1] = qx[i] * py[i]; A[i][2] = qx[i];
+      A[i][3] = qy[i] * px[i]; A[i][4] = qy[i] * py[i]; A[i][5] = qy[i];
+      A[i][6] = px[i];         A[i][7] = py[i];         A[i][8] = 1.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 9; a++)
+#pragma unroll
+      for (int b = a; b < 9; b++) {      // fundamental_solver.cc:30, the upper triangle
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < SAMPLE; i++) s = s + A[i][a] * A[i][b];
+        S[a][b] = s;
+      }
+  }
+  double f[9];
+  smallest_eigenvector<9>(S, SWEEPS9, f);     // fundamental_solver.cc:32-38: last column of V
+  // rank two (fundamental_solver.cc:44-52): U diag(s0, s1, 0) V^T = G - (G v) v^T with v the singular
+  // vector of the smallest singular value, i.e. the eigenvector of G^T G of the smallest eigenvalue
+  double M[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = a; b < 3; b++) M[a][b] = (f[a] * f[b] + f[3 + a] * f[3 + b]) + f[6 + a] * f[6 + b];
+  double v[3];
+  smallest_eigenvector<3>(M, SWEEPS3, v);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const double gv = (f[3 * r] * v[0] + f[3 * r + 1] * v[1]) + f[3 * r + 2] * v[2];
+#pragma unroll
+    for (int c = 0; c < 3; c++) F[3 * r + c] = f[3 * r + c] - gv * v[c];
+  }
+}
+
+// fundamental_solver.hpp:59-72
+__device__ __forceinline__ double epipolar_line_error(double x, double y, double xp, double yp, const double (&F)[9]) {
+#pragma clang fp contract(off)
+  const double lx = (F[0] * x + F[1] * y) + F[2];
+  const double ly = (F[3] * x + F[4] * y) + F[5];
+  const double rx = (F[0] * xp + F[3] * yp) + F[6];
+  const double ry = (F[1] * xp + F[4] * yp) + F[7];
+  const double rz = (F[2] * xp + F[5] * yp) + F[8];
+  const double num = (rx * x + ry * y) + rz;
+  const double deno = 1.0 / (lx * lx + ly * ly) + 1.0 / (rx * rx + ry * ry);
+  return (num * num) * deno;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 256 rounds of every unfinished pair: thread = one round.  grid: (4, pairs), 64 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HYP_THREADS) void k_geo_rounds(const GeoPair* __restrict__ pairs, uint32_t first_round) {
+#pragma clang fp contract(off)
+  const GeoPair P = pairs[blockIdx.y];
+  const GeoState* st = P.state;
+  if (st->done) return;
+  const uint32_t slot = blockIdx.x * HYP_THREADS + threadIdx.x;
+  const uint32_t round = first_round + slot;
+  if (round >= st->rounds_limit) return;   // the limit only ever comes down: never looked at
+  const uint32_t n = (uint32_t)P.n;
+  const uint64_t key = round_key(P.stream, round);
+  // ransac.hpp:34-59: a rotating offset, then selection sampling in index order
+  int idx[SAMPLE];
+#pragma unroll
+  for (int k = 0; k < SAMPLE; k++) idx[k] = 0;
+  {
+    const uint32_t offset = (uint32_t)(stream_word(key, 0) % (uint64_t)(n + 1));
+    int selected = 0;
+    for (uint32_t i = 0; i < n && selected < SAMPLE; i++) {
+      const double select_probability = (double)(SAMPLE - selected) / (double)(n - i);
+      const double u = (double)(stream_word(key, 1 + i) >> 11) * 0x1.0p-53;
+      if (u < select_probability) {
+        const int pick = (int)((offset + i) % n);
+#pragma unroll
+        for (int k = 0; k < SAMPLE; k++) idx[k] = selected == k ? pick : idx[k];
+        selected++;
+      }
+    }
+  }
+  double px[SAMPLE], py[SAMPLE], qx[SAMPLE], qy[SAMPLE];
+#pragma unroll
+  for (int k = 0; k < SAMPLE; k++) {
+    const double2 a = reinterpret_cast<const double2*>(P.lhs)[idx[k]];
+    const double2 b = reinterpret_cast<const double2*>(P.rhs)[idx[k]];
+    px[k] = a.x; py[k] = a.y; qx[k] = b.x; qy[k] = b.y;
+  }
+  double F[9];
+  fit_eight(px, py, qx, qy, F);
+  // ransac.hpp:112-124: the sample is in unexamined, everything else unless its error exceeds 3.84
+  uint32_t count = SAMPLE;
+  for (uint32_t i = 0; i < n; i++) {
+    const double2 a = reinterpret_cast<const double2*>(P.lhs)[i];
+    const double2 b = reinterpret_cast<const double2*>(P.rhs)[i];
+    bool in_sample = false;
+#pragma unroll
+    for (int k = 0; k < SAMPLE; k++) in_sample |= idx[k] == (int)i;
+    const double err = epipolar_line_error(a.x, a.y, b.x, b.y, F);
+    count += (!in_sample && !(err > 3.84)) ? 1u : 0u;
+  }
+  P.hyp_count[slot] = count;
+#pragma unroll
+  for (int k = 0; k < 9; k++) P.hyp_F[(size_t)slot * 9 + k] = F[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// ransac.hpp:126-142 over the launch's results in round order.  One thread per pair.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restrict__ pairs, int n_pairs, uint32_t first_round,
+                                                        uint32_t* __restrict__ unfinished) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n_pairs) return;
+  const GeoPair P = pairs[p];
+  GeoState* st = P.state;
+  if (st->done) return;
+  uint32_t limit = st->rounds_limit, done_rounds = st->rounds_done, best = st->best_count;
+  bool finished = false;
+  for (uint32_t slot = 0; slot < (uint32_t)ROUNDS_PER_LAUNCH && !finished; slot++) {
+    if (!(limit > done_rounds)) {      // while (N > sample_count)
+      finished = true;
+      break;
+    }
+    const uint32_t count = P.hyp_count[slot];
+    done_rounds++;
+    if (count == (uint32_t)P.n) {      // :127-131: everything is an inlier
+      for (int k = 0; k < 9; k++) st->best_F[k] = P.hyp_F[(size_t)slot * 9 + k];
+      best = count;
+      finished = true;
+      break;
+    }
+    limit = min(limit, P.rounds_needed[count]);
+    if (count > best) {                // :138-141
+      for (int k = 0; k < 9; k++) st->best_F[k] = P.hyp_F[(size_t)slot * 9 + k];
+      best = count;
+    }
+  }
+  if (!(limit > done_rounds)) finished = true;
+  st->rounds_limit = limit;
+  st->rounds_done = done_rounds;
+  st->best_count = best;
+  st->done = finished ? 1u : 0u;
+  if (!finished) atomicAdd(unfinished, 1u);
+  (void)first_round;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sfm_main.cc:32-42: the matches whose error under the final model is below 3.84.
+// grid: (ceil(largest n / 256), pairs)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_geo_classify(const GeoPair* __restrict__ pairs) {
+#pragma clang fp contract(off)
+  const GeoPair P = pairs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P.n) return;
+  double F[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) F[k] = P.state->best_F[k];
+  const double2 a = reinterpret_cast<const double2*>(P.lhs)[i];
+  const double2 b = reinterpret_cast<const double2*>(P.rhs)[i];
+  const bool in = epipolar_line_error(a.x, a.y, b.x, b.y, F) < 3.84;
+  P.flags[i] = in ? 1 : 0;
+  const unsigned long long m = __ballot(in);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(P.n_inliers, (uint32_t)__popcll(m));
+}
+
+}  // namespace sfm_geometry
+
+#endif  // SFM_AMD_CSRC_GEOMETRY_KERNELS_HPP_

@@ -1,0 +1,157 @@
+// Host side of sfm_hip_geometry_verify_pairs (include/sfm_hip.h): uploads the matches' pixel
+// positions, runs the RANSAC rounds in launches of 256 until every pair has stopped, classifies.
+#include "ctx.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "geometry_kernels.hpp"
+
+using namespace sfm_geometry;
+using namespace sfm_host;
+
+namespace {
+
+struct Scratch {   // a device allocation that lives for one call
+  void* p = nullptr;
+  ~Scratch() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+// ransac.hpp:128-131 for every possible inlier count of a pair with n matches: how many rounds
+// are enough once a model with that many inliers has been seen, never more than the round limit.
+// Computed here, with the host's math library, because it is the same library the reference's
+// std::log / std::pow resolve to: the stopping round is then the reference's to the unit.
+void fill_rounds_needed(size_t n, uint32_t* table) {
+  for (size_t c = 0; c <= n; c++) {
+    const double epsilon = (n - c) * 1.0 / n;
+    const double t = std::ceil(std::log(1 - 0.99) / std::log(1 - std::pow(1 - epsilon, SAMPLE)));
+    // few inliers: w^8 vanishes against 1, the quotient is -infinity, and the reference's
+    // conversion of that to size_t leaves its N as it is
+    table[c] = (t >= 0.0 && t < (double)MAX_ROUNDS) ? (uint32_t)t : MAX_ROUNDS;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64_t* match_offsets, const double* lhs_xy,
+                                  const double* rhs_xy, uint64_t seed, int64_t first_pair_index, double* out_F,
+                                  uint8_t* out_inlier_flags, int32_t* out_inlier_counts, int32_t* out_rounds) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (n_pairs < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative pair count");
+  if (n_pairs == 0) return SFM_HIP_OK;
+  if (!match_offsets || !out_F || !out_inlier_counts) return fail(ctx, SFM_HIP_ERR_INVALID, "null offsets or output buffer");
+  if (match_offsets[0] != 0) return fail(ctx, SFM_HIP_ERR_INVALID, "match_offsets must start at 0");
+  for (int32_t p = 0; p < n_pairs; p++)
+    if (match_offsets[p + 1] < match_offsets[p] || match_offsets[p + 1] - match_offsets[p] > 0x7FFFFFFF)
+      return fail(ctx, SFM_HIP_ERR_INVALID, "match_offsets must ascend by less than 2^31 per pair");
+  const int64_t total = match_offsets[n_pairs];
+  if (total > 0 && (!lhs_xy || !rhs_xy || !out_inlier_flags))
+    return fail(ctx, SFM_HIP_ERR_INVALID, "null positions or flag buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->upload_stream;
+
+  // pairs with fewer than eight matches cannot be sampled (ransac.hpp:38-42): nothing is computed
+  std::vector<int32_t> live;
+  for (int32_t p = 0; p < n_pairs; p++) {
+    out_inlier_counts[p] = 0;
+    if (out_rounds) out_rounds[p] = 0;
+    for (int k = 0; k < 9; k++) out_F[(size_t)p * 9 + k] = 0.0;
+    if (match_offsets[p + 1] - match_offsets[p] >= SAMPLE) live.push_back(p);
+  }
+  if (total > 0) std::fill(out_inlier_flags, out_inlier_flags + total, (uint8_t)0);
+  if (live.empty()) return SFM_HIP_OK;
+  const int n_live = (int)live.size();
+
+  // one table of rounds needed per distinct match count
+  std::map<int64_t, size_t> table_at;
+  size_t table_words = 0;
+  for (int32_t p : live) {
+    const int64_t n = match_offsets[p + 1] - match_offsets[p];
+    if (table_at.emplace(n, table_words).second) table_words += (size_t)n + 1;
+  }
+  std::vector<uint32_t> tables(table_words);
+  for (const auto& kv : table_at) fill_rounds_needed((size_t)kv.first, tables.data() + kv.second);
+
+  Scratch d_lhs, d_rhs, d_tables, d_state, d_hyp_F, d_hyp_count, d_flags, d_counts, d_pairs, d_unfinished;
+  HIP_TRY(ctx, hipMalloc(&d_lhs.p, (size_t)total * 16));
+  HIP_TRY(ctx, hipMalloc(&d_rhs.p, (size_t)total * 16));
+  HIP_TRY(ctx, hipMalloc(&d_tables.p, tables.size() * 4));
+  HIP_TRY(ctx, hipMalloc(&d_state.p, (size_t)n_live * sizeof(GeoState)));
+  HIP_TRY(ctx, hipMalloc(&d_hyp_F.p, (size_t)n_live * ROUNDS_PER_LAUNCH * 9 * sizeof(double)));
+  HIP_TRY(ctx, hipMalloc(&d_hyp_count.p, (size_t)n_live * ROUNDS_PER_LAUNCH * 4));
+  HIP_TRY(ctx, hipMalloc(&d_flags.p, (size_t)total));
+  HIP_TRY(ctx, hipMalloc(&d_counts.p, (size_t)n_live * 4));
+  HIP_TRY(ctx, hipMalloc(&d_pairs.p, (size_t)n_live * sizeof(GeoPair)));
+  HIP_TRY(ctx, hipMalloc(&d_unfinished.p, 4));
+  HIP_TRY(ctx, hipMemcpyAsync(d_lhs.p, lhs_xy, (size_t)total * 16, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_rhs.p, rhs_xy, (size_t)total * 16, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tables.p, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(d_flags.p, 0, (size_t)total, st));
+  HIP_TRY(ctx, hipMemsetAsync(d_counts.p, 0, (size_t)n_live * 4, st));
+
+  std::vector<GeoState> states((size_t)n_live);
+  std::vector<GeoPair> pairs((size_t)n_live);
+  int max_n = 0;
+  for (int k = 0; k < n_live; k++) {
+    const int32_t p = live[(size_t)k];
+    const int64_t at = match_offsets[p], n = match_offsets[p + 1] - at;
+    GeoState& s = states[(size_t)k];
+    for (double& v : s.best_F) v = 0.0;
+    s.rounds_limit = MAX_ROUNDS;
+    s.rounds_done = 0;
+    s.best_count = 0;
+    s.done = 0;
+    GeoPair& g = pairs[(size_t)k];
+    g.lhs = (const double*)d_lhs.p + 2 * at;
+    g.rhs = (const double*)d_rhs.p + 2 * at;
+    g.rounds_needed = (const uint32_t*)d_tables.p + table_at.at(n);
+    g.state = (GeoState*)d_state.p + k;
+    g.hyp_F = (double*)d_hyp_F.p + (size_t)k * ROUNDS_PER_LAUNCH * 9;
+    g.hyp_count = (uint32_t*)d_hyp_count.p + (size_t)k * ROUNDS_PER_LAUNCH;
+    g.flags = (uint8_t*)d_flags.p + at;
+    g.n_inliers = (uint32_t*)d_counts.p + k;
+    g.n = (int32_t)n;
+    g.pad_ = 0;
+    g.stream = pair_stream(seed, (uint64_t)(first_pair_index + p));
+    max_n = std::max(max_n, (int)n);
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d_state.p, states.data(), states.size() * sizeof(GeoState), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_pairs.p, pairs.data(), pairs.size() * sizeof(GeoPair), hipMemcpyHostToDevice, st));
+
+  const GeoPair* dp = (const GeoPair*)d_pairs.p;
+  for (uint32_t first = 0; first < MAX_ROUNDS; first += ROUNDS_PER_LAUNCH) {
+    HIP_TRY(ctx, hipMemsetAsync(d_unfinished.p, 0, 4, st));
+    hipLaunchKernelGGL(k_geo_rounds, dim3(ROUNDS_PER_LAUNCH / HYP_THREADS, (unsigned)n_live), dim3(HYP_THREADS), 0, st, dp, first);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)((n_live + 63) / 64)), dim3(64), 0, st, dp, n_live, first,
+                       (uint32_t*)d_unfinished.p);
+    HIP_TRY(ctx, hipGetLastError());
+    uint32_t unfinished = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&unfinished, d_unfinished.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (unfinished == 0) break;
+  }
+  hipLaunchKernelGGL(k_geo_classify, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_live), dim3(256), 0, st, dp);
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<uint32_t> counts((size_t)n_live);
+  HIP_TRY(ctx, hipMemcpyAsync(states.data(), d_state.p, states.size() * sizeof(GeoState), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(out_inlier_flags, d_flags.p, (size_t)total, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  for (int k = 0; k < n_live; k++) {
+    const int32_t p = live[(size_t)k];
+    for (int c = 0; c < 9; c++) out_F[(size_t)p * 9 + c] = states[(size_t)k].best_F[c];
+    out_inlier_counts[p] = (int32_t)counts[(size_t)k];
+    if (out_rounds) out_rounds[p] = (int32_t)states[(size_t)k].rounds_done;
+  }
+  return SFM_HIP_OK;
+}
+
+}  // extern "C"

@@ -121,6 +121,39 @@ def make_repetitive_set(n_images, n_features, shared_fraction, copies, seed, sig
     return out
 
 
+def uniform(n, seed):
+    """n doubles in [0, 1) from the splitmix64 stream."""
+    return (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+
+
+def make_two_view_matches(n, inlier_fraction, seed, noise=0.5, width=1600.0, height=1200.0):
+    """n matches (lhs_xy, rhs_xy, is_inlier) between two views of one rigid scene: a fraction of
+    them are projections of common 3-D points into two pinhole cameras (the second one shifted and
+    turned about the vertical axis by fixed rational amounts: no trigonometric function involved),
+    with uniform pixel noise of +-noise; the rest pair up unrelated positions.  Pixel coordinates,
+    as the reference's key points are."""
+    n_in = int(round(inlier_fraction * n))
+    f = 1200.0
+    cx, cy = width / 2.0, height / 2.0
+    u = uniform(8 * n, _stream(seed, 31)).reshape(8, n)
+    X = (u[0] - 0.5) * 8.0
+    Y = (u[1] - 0.5) * 6.0
+    Z = 6.0 + u[2] * 6.0
+    lhs = np.stack([f * X / Z + cx, f * Y / Z + cy], axis=1)
+    c, s = 0.96, 0.28                      # cos, sin of the turn: 0.96^2 + 0.28^2 = 1
+    X2 = c * X + s * Z - 1.5
+    Z2 = -s * X + c * Z + 0.4
+    rhs = np.stack([f * X2 / Z2 + cx, f * (Y + 0.1) / Z2 + cy], axis=1)
+    lhs += (u[3:5].T - 0.5) * 2.0 * noise
+    rhs += (u[5:7].T - 0.5) * 2.0 * noise
+    is_in = np.zeros(n, bool)
+    order = permutation(n, _stream(seed, 32))
+    is_in[order[:n_in]] = True
+    w = uniform(2 * n, _stream(seed, 33)).reshape(n, 2)
+    rhs[~is_in] = (w * np.array([width, height]))[~is_in]
+    return lhs, rhs, is_in
+
+
 def keypoints(n_features, image_id):
     """(x, y) = (feature index, image id): results can be checked from observations alone."""
     kp = np.empty((n_features, 2), np.float64)
