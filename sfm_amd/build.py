@@ -64,9 +64,9 @@ def build_host(force=False):
     common = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith((".hpp", ".cc"))]
     inc = ["-I", HOST, "-I", os.path.join(ROOT, "include")]
     link = ["-L", LIBDIR, "-lsfm_hip", "-Wl,-rpath,$ORIGIN", "-pthread"]
-    lib_srcs = [os.path.join(HOST, f) for f in ("hip_brute_force_matcher.cc", "hip_cascade_hash_matcher.cc", "exhaustive_pair_builder.cc", "sfm_data_io.cc", "sfm_data_json.cc")
+    lib_srcs = [os.path.join(HOST, f) for f in ("hip_brute_force_matcher.cc", "hip_cascade_hash_matcher.cc", "hip_geometry_filter.cc", "exhaustive_pair_builder.cc", "sfm_data_io.cc", "sfm_data_json.cc")
                 if os.path.exists(os.path.join(HOST, f))]
-    for name in ("feature_match_main", "match_set_bench"):
+    for name in ("feature_match_main", "match_set_bench", "geometry_filter_main"):
         src = os.path.join(HOST, name + ".cc")
         if not os.path.exists(src):
             continue

@@ -252,3 +252,42 @@ def test_gpu_cascade_three_shards_on_one_gpu(tmp_path):
     pairs = [(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]]
     whole = _cascade_expected(images, pairs, True)
     assert _check_cascade_records(read_sfm_bin(path), images, whole) > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [1, 3])
+def test_gpu_geometry_filter_program(tmp_path, devices):
+    """GeometryFilter (src/sfm_main.cc:259-282) through the C++ drop-in: pairs with more than 30
+    inliers keep exactly their inliers, the others disappear; one shard and three shards agree."""
+    from oracle import geometry
+    exe = os.path.join(ROOT, "sfm_amd", "lib", "geometry_filter_main")
+    assert os.path.exists(exe), "run python -m sfm_amd.build"
+    images = {i: synth.rootsift_rows(4, 50 + i) for i in (1, 2, 5, 9)}
+    kps = {i: synth.keypoints(4, i) for i in images}
+    spec = {(1, 2): (400, 0.8), (1, 5): (60, 0.1), (1, 9): (5, 1.0), (2, 5): (900, 0.6), (2, 9): (0, 1.0), (5, 9): (120, 0.9)}
+    matches, views = {}, {}
+    for k, (pair, (n, frac)) in enumerate(sorted(spec.items())):
+        l, r, _ = synth.make_two_view_matches(n, frac, seed=300 + k)
+        matches[pair] = (l, r, np.arange(n, dtype=np.int64), np.arange(n, dtype=np.int64)[::-1].copy())
+        views[pair] = (l, r)
+    path = str(tmp_path / "sfm_data.bin")
+    write_sfm_bin(path, images, kps, matches)
+    env = dict(os.environ, SFM_HIP_OVERSUBSCRIBE="1")
+    out = subprocess.run([exe, path, "--seed", "77", "--devices", str(devices)], check=True, env=env,
+                         stdout=subprocess.PIPE, text=True).stdout
+    assert out.startswith("6Match \n") and out.count("inlier : ") == 6
+    data = read_sfm_bin(path)
+    kept = {}
+    for k, pair in enumerate(sorted(spec)):
+        l, r = views[pair]
+        ok, _, flags, _ = geometry.compute_fundamental(l, r, seed=77, pair=k)
+        assert "inlier : %d\n" % int(flags.sum()) in out
+        if ok:
+            kept[pair] = np.flatnonzero(flags)
+    assert sorted(data["matches"]) == sorted(kept) and len(kept) >= 3
+    for pair, idx in kept.items():
+        rec = data["matches"][pair]
+        l, r = views[pair]
+        assert rec["li"].tolist() == idx.tolist()
+        assert rec["ri"].tolist() == (len(l) - 1 - idx).tolist()
+        assert rec["lx"].tolist() == l[idx, 0].tolist() and rec["ry"].tolist() == r[idx, 1].tolist()
