@@ -3,8 +3,10 @@
 // (uploads, GPU matching on every visible device, Match records built on the host) and report
 // pairs per second over the whole call.
 //
-//   match_set_bench <n_images> <n_features> [planted_fraction=0.5] [devices=0] [engine=-1]
-//   (engine: -1 library default / SFM_HIP_ENGINE, 0 fp32 matrix instructions, 1 split fp16)
+//   match_set_bench <n_images> <n_features> [planted_fraction=0.5] [devices=0] [engine=-1] [matcher=brute]
+//   (engine: -1 library default / SFM_HIP_ENGINE, 0 fp32 matrix instructions, 1 split fp16;
+//    matcher: brute | cascade -- with cascade every shared scene row appears twice per image with
+//    little noise: that matcher reports nothing unless a query has two near-duplicate candidates)
 //
 // Images share a pool of "scene" descriptors (non-negative rows of unit length, as RootSIFT
 // produces: vlfeat_feature_extractor.cc:15-22); each image takes planted_fraction of its rows from
@@ -20,7 +22,11 @@
 #include <vector>
 
 #include "exhaustive_pair_builder.hpp"
+#include <memory>
+#include <string>
+
 #include "hip_brute_force_matcher.hpp"
+#include "hip_cascade_hash_matcher.hpp"
 #include "sfm_data.hpp"
 
 namespace {
@@ -57,11 +63,14 @@ int main(int argc, char** argv) {
   const double planted = argc > 3 ? std::atof(argv[3]) : 0.5;
   const int devices = argc > 4 ? std::atoi(argv[4]) : 0;
   const int engine = argc > 5 ? std::atoi(argv[5]) : -1;
-  const int n_planted = (int)(planted * n_feat);
+  const bool cascade = argc > 6 && std::string(argv[6]) == "cascade";
+  const int copies = cascade ? 2 : 1;
+  const double sigma = cascade ? 0.002 : 0.01;
+  const int n_planted = (int)(planted * n_feat) / copies * copies;   // rows of an image taken from the pool
 
   Rng rng{12345};
-  std::vector<float> pool((size_t)n_planted * 128);
-  for (int r = 0; r < n_planted; r++) scene_row(rng, &pool[(size_t)r * 128]);
+  std::vector<float> pool((size_t)(n_planted / copies) * 128);
+  for (int r = 0; r < n_planted / copies; r++) scene_row(rng, &pool[(size_t)r * 128]);
 
   SfMData data;
   for (int id = 0; id < n_images; id++) {
@@ -73,7 +82,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < n_feat; r++) {
       float* row = &raw[(size_t)order[r] * 128];
       if (r < n_planted) {
-        for (int k = 0; k < 128; k++) row[k] = pool[(size_t)r * 128 + k] + (float)(0.01 * rng.noise());
+        for (int k = 0; k < 128; k++) row[k] = pool[(size_t)(r / copies) * 128 + k] + (float)(sigma * rng.noise());
       } else {
         scene_row(rng, row);
       }
@@ -88,8 +97,15 @@ int main(int argc, char** argv) {
 
   std::set<Pair> pairs;
   ExhaustivePairBuilder().BuildPair(data, pairs);
-  HipBruteForceMatcher matcher(devices, 0.8, /*print_progress=*/false);
-  matcher.set_engine(engine);
+  std::shared_ptr<FeatureMatcherInterface> matcher_ptr;
+  if (cascade) {
+    matcher_ptr = std::make_shared<HipCascadeHashMatcher>(devices, /*print_progress=*/false);
+  } else {
+    auto brute = std::make_shared<HipBruteForceMatcher>(devices, 0.8, /*print_progress=*/false);
+    brute->set_engine(engine);
+    matcher_ptr = brute;
+  }
+  FeatureMatcherInterface& matcher = *matcher_ptr;
   // SFM_MATCH_BENCH_REPEAT=n: call Match n times and report the last (the first call of a
   // process also pays for loading the GPU code and creating the work space)
   const char* rep_env = std::getenv("SFM_MATCH_BENCH_REPEAT");
@@ -107,8 +123,8 @@ int main(int argc, char** argv) {
     for (const Match& m : list)   // keypoints encode (feature index, image id)
       if (m.lhs_observation.x() != (double)m.lhs_idx || m.rhs_observation.y() != (double)pair.second) wrong++;
   }
-  std::printf("{\"engine\": %d, \"images\": %d, \"features\": %d, \"pairs\": %zu, \"seconds\": %.4f, \"pairs_per_s\": %.1f, "
+  std::printf("{\"matcher\": \"%s\", \"engine\": %d, \"images\": %d, \"features\": %d, \"pairs\": %zu, \"seconds\": %.4f, \"pairs_per_s\": %.1f, "
               "\"matches\": %zu, \"matches_per_pair\": %.1f, \"observation_mismatches\": %zu}\n",
-              engine, n_images, n_feat, pairs.size(), sec, pairs.size() / sec, total, (double)total / pairs.size(), wrong);
+              cascade ? "cascade" : "brute", engine, n_images, n_feat, pairs.size(), sec, pairs.size() / sec, total, (double)total / pairs.size(), wrong);
   return wrong ? 1 : 0;
 }
