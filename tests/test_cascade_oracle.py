@@ -223,3 +223,21 @@ def test_mean_uses_the_reference_view_of_the_block():
     sums = cascade.image_column_sums(x)
     # runs have length 4: the first 32 runs cover row 0 (sum 4 each), the rest are zero
     assert sums.tolist() == [4.0] * 32 + [0.0] * 96
+
+
+def test_golden_cases_reproduce():
+    """tests/golden/cascade_cases.json: the pair (generator, oracle) gives the same bits here as where
+    the file was written (tests/golden/make_golden_next.py)."""
+    import json
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_next as g
+    with open(os.path.join(ROOT, "tests", "golden", "cascade_cases.json")) as f:
+        want = json.load(f)
+    p, s = cascade.projection()
+    assert g.digest(p.view(np.uint32), s.view(np.uint32)) == want["projection_bits_sha256"]
+    for c, w in zip(g.CASCADE_CASES, want["cases"]):
+        assert g.cascade_case(c) == w, c[0]
+    assert sum(pr["count"] for w in want["cases"] for pr in w["pairs"]) > 300

@@ -65,3 +65,23 @@ def test_fewer_than_eight_matches():
     l, r, _ = synth.make_two_view_matches(7, 1.0, seed=1)
     ok, F, flags, rounds = geometry.compute_fundamental(l, r)
     assert not ok and rounds == 0 and not F.any() and not flags.any()
+
+
+def test_golden_cases_reproduce():
+    """tests/golden/geometry_cases.json: the pair (generator, oracle) gives the same bits here as where
+    the file was written (tests/golden/make_golden_next.py)."""
+    import json
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_next as g
+    with open(os.path.join(ROOT, "tests", "golden", "geometry_cases.json")) as f:
+        want = json.load(f)
+    got = [g.geometry_case(c) for c in g.GEOMETRY_CASES]
+    assert got == want["cases"]
+    by = {w["name"]: w for w in want["cases"]}
+    assert by["clean"]["rounds"] == 1 and by["clean"]["n_inliers"] == 50      # everything fits: stop at once
+    assert by["too_few"]["rounds"] == 0 and not by["too_few"]["ok"]
+    assert by["hopeless"]["rounds"] == 4096 and not by["hopeless"]["ok"]
+    assert by["mostly_inliers"]["ok"] and by["mostly_inliers"]["rounds"] < 200
