@@ -86,7 +86,8 @@ void sample_std(size_t n, uint32_t seed, int* out) {
 // ---- the fit ---------------------------------------------------------------------------------
 // Cyclic Jacobi on a symmetric n x n matrix of which only the upper triangle (S[a][b], a <= b) is
 // used and kept: it becomes (nearly) diagonal, V receives the eigenvectors.  A fixed number of
-// sweeps; the rotation in the form that updates the two diagonal entries by t * S[p][q] and every
+// sweeps, in which an off-diagonal entry too small to change either of its diagonal entries
+// (100 |a_pq| is lost when added to them) is set to zero instead of rotated away; the rotation in the form that updates the two diagonal entries by t * S[p][q] and every
 // other affected entry as g - s (h + g tau), h + s (g - h tau).
 template <int N>
 void jacobi(double (&S)[N][N], double (&V)[N][N], int sweeps) {
@@ -97,6 +98,12 @@ void jacobi(double (&S)[N][N], double (&V)[N][N], int sweeps) {
       for (int q = p + 1; q < N; q++) {
         const double apq = S[p][q];
         if (apq == 0.0) continue;
+        // an entry that no longer registers against either diagonal entry is simply dropped
+        const double small = 100.0 * std::fabs(apq);
+        if (std::fabs(S[p][p]) + small == std::fabs(S[p][p]) && std::fabs(S[q][q]) + small == std::fabs(S[q][q])) {
+          S[p][q] = 0.0;
+          continue;
+        }
         const double theta = (S[q][q] - S[p][p]) / (2.0 * apq);
         double t = 1.0 / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
         if (theta < 0.0) t = -t;

@@ -329,25 +329,31 @@ class Matcher:
         self._check(self._lib.sfm_hip_cascade_reset_stats(self._h), "sfm_hip_cascade_reset_stats")
 
     # ---- geometric verification -----------------------------------------------------------
-    def geometry_verify_pairs(self, matches, seed=0, first_pair_index=0):
-        """matches: [(lhs_xy [n, 2], rhs_xy [n, 2])] per pair.  Returns per pair
-        (ok, F [3, 3], inlier flags uint8 [n], rounds) as ComputeFundamentalMatrix decides them."""
-        sizes = [len(l) for l, _ in matches]
-        offsets = np.zeros(len(matches) + 1, np.int64)
-        offsets[1:] = np.cumsum(sizes)
-        total = int(offsets[-1])
-        lhs = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float64).reshape(-1, 2) for l, _ in matches] or
-                                                  [np.zeros((0, 2))]), dtype=np.float64)
-        rhs = np.ascontiguousarray(np.concatenate([np.asarray(r, np.float64).reshape(-1, 2) for _, r in matches] or
-                                                  [np.zeros((0, 2))]), dtype=np.float64)
-        F = np.zeros((len(matches), 9), np.float64)
+    def geometry_verify_flat(self, offsets, lhs_xy, rhs_xy, seed=0, first_pair_index=0):
+        """The C call on flat arrays: offsets int64 [n_pairs + 1], positions float64 [total, 2].
+        Returns (F [n_pairs, 9], flags uint8 [total], counts int32 [n_pairs], rounds int32 [n_pairs])."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        lhs = np.ascontiguousarray(lhs_xy, dtype=np.float64)
+        rhs = np.ascontiguousarray(rhs_xy, dtype=np.float64)
+        n, total = len(offsets) - 1, int(offsets[-1])
+        F = np.zeros((n, 9), np.float64)
         flags = np.zeros(max(total, 1), np.uint8)
-        counts = np.zeros(max(len(matches), 1), np.int32)
-        rounds = np.zeros(max(len(matches), 1), np.int32)
-        self._check(self._lib.sfm_hip_geometry_verify_pairs(self._h, len(matches), offsets.ctypes.data, lhs.ctypes.data,
+        counts = np.zeros(max(n, 1), np.int32)
+        rounds = np.zeros(max(n, 1), np.int32)
+        self._check(self._lib.sfm_hip_geometry_verify_pairs(self._h, n, offsets.ctypes.data, lhs.ctypes.data,
                                                             rhs.ctypes.data, int(seed), int(first_pair_index),
                                                             F.ctypes.data, flags.ctypes.data, counts.ctypes.data,
                                                             rounds.ctypes.data), "sfm_hip_geometry_verify_pairs")
+        return F, flags[:total], counts[:n], rounds[:n]
+
+    def geometry_verify_pairs(self, matches, seed=0, first_pair_index=0):
+        """matches: [(lhs_xy [n, 2], rhs_xy [n, 2])] per pair.  Returns per pair
+        (ok, F [3, 3], inlier flags uint8 [n], rounds) as ComputeFundamentalMatrix decides them."""
+        offsets = np.zeros(len(matches) + 1, np.int64)
+        offsets[1:] = np.cumsum([len(l) for l, _ in matches])
+        lhs = np.concatenate([np.asarray(l, np.float64).reshape(-1, 2) for l, _ in matches] or [np.zeros((0, 2))])
+        rhs = np.concatenate([np.asarray(r, np.float64).reshape(-1, 2) for _, r in matches] or [np.zeros((0, 2))])
+        F, flags, counts, rounds = self.geometry_verify_flat(offsets, lhs, rhs, seed, first_pair_index)
         return [(int(counts[k]) > 30, F[k].reshape(3, 3).copy(), flags[offsets[k]:offsets[k + 1]].copy(), int(rounds[k]))
                 for k in range(len(matches))]
 

@@ -83,6 +83,9 @@ struct sfm_hip_ctx {
   size_t batch_bytes_limit = (size_t)6 << 30;  // work space per batch
   int max_pairs_per_batch = 256;
 
+  // geometric verification: grow-only device buffers kept between calls
+  sfm_host::DevBuf geometry_buffers[11];
+
   // cascade-hash matcher
   float* cascade_projection = nullptr;   // device: [128 + 60][128] projection rows, then the 128-float mean
   bool cascade_has_projection = false;

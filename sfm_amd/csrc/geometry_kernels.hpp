@@ -6,7 +6,7 @@
 //
 // The reference runs its rounds one after the other because the number of rounds shrinks as better
 // models turn up.  Here a launch evaluates 256 rounds of every unfinished pair at once (one thread per
-// round: sample, fit, count), then one thread per pair replays the reference's bookkeeping over those
+// round: sample and fit in one kernel, count in another), then one thread per pair replays the reference's bookkeeping over those
 // 256 results in round order -- which yields exactly what the sequential loop would, the rounds
 // past the stopping point being wasted work -- and the host launches again while any pair is unfinished.
 //
@@ -45,6 +45,7 @@ struct GeoPair {
   const uint32_t* rounds_needed;   // [n + 1]: ransac.hpp:128-131 as a function of the inlier count
   GeoState* state;
   double* hyp_F;                   // [256][9] models of the current launch
+  int32_t* hyp_idx;                // [256][8] the matches they were fitted to
   uint32_t* hyp_count;             // [256] their inlier counts
   uint8_t* flags;                  // [n] final classification
   uint32_t* n_inliers;
@@ -73,6 +74,13 @@ __device__ __forceinline__ void rotate_pq(double (&S)[N][N], double (&V)[N][N]) 
 #pragma clang fp contract(off)
   const double apq = S[P][Q];
   if (apq == 0.0) return;
+  // an entry that no longer registers against either diagonal entry is simply dropped; once every
+  // lane of the wavefront is there, the later sweeps cost next to nothing
+  const double small = 100.0 * fabs(apq);
+  if (fabs(S[P][P]) + small == fabs(S[P][P]) && fabs(S[Q][Q]) + small == fabs(S[Q][Q])) {
+    S[P][Q] = 0.0;
+    return;
+  }
   const double theta = (S[Q][Q] - S[P][P]) / (2.0 * apq);
   double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
   if (theta < 0.0) t = -t;
@@ -193,9 +201,14 @@ __device__ __forceinline__ double epipolar_line_error(double x, double y, double
 }
 
 // ---------------------------------------------------------------------------------------------
-// 256 rounds of every unfinished pair: thread = one round.  grid: (4, pairs), 64 threads.
+// 256 rounds of every unfinished pair, in two kernels because they want opposite things from the
+// register file: the fit keeps two matrices in registers and runs one wavefront per SIMD, the
+// count needs few registers and hides its divisions behind eight.
+//   k_geo_fit    thread = one round: sample, fit.  grid: (4, pairs), 64 threads.
+//   k_geo_count  thread = one round, workgroup = the 256 rounds of a pair: the matches pass through
+//                LDS in tiles, every thread measures each of them against its model.  grid: (pairs).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HYP_THREADS) void k_geo_rounds(const GeoPair* __restrict__ pairs, uint32_t first_round) {
+__global__ __launch_bounds__(HYP_THREADS) void k_geo_fit(const GeoPair* __restrict__ pairs, uint32_t first_round) {
 #pragma clang fp contract(off)
   const GeoPair P = pairs[blockIdx.y];
   const GeoState* st = P.state;
@@ -232,20 +245,52 @@ __global__ __launch_bounds__(HYP_THREADS) void k_geo_rounds(const GeoPair* __res
   }
   double F[9];
   fit_eight(px, py, qx, qy, F);
-  // ransac.hpp:112-124: the sample is in unexamined, everything else unless its error exceeds 3.84
-  uint32_t count = SAMPLE;
-  for (uint32_t i = 0; i < n; i++) {
-    const double2 a = reinterpret_cast<const double2*>(P.lhs)[i];
-    const double2 b = reinterpret_cast<const double2*>(P.rhs)[i];
-    bool in_sample = false;
-#pragma unroll
-    for (int k = 0; k < SAMPLE; k++) in_sample |= idx[k] == (int)i;
-    const double err = epipolar_line_error(a.x, a.y, b.x, b.y, F);
-    count += (!in_sample && !(err > 3.84)) ? 1u : 0u;
-  }
-  P.hyp_count[slot] = count;
 #pragma unroll
   for (int k = 0; k < 9; k++) P.hyp_F[(size_t)slot * 9 + k] = F[k];
+#pragma unroll
+  for (int k = 0; k < SAMPLE; k++) P.hyp_idx[(size_t)slot * SAMPLE + k] = idx[k];
+}
+
+constexpr int COUNT_TILE = 256;
+
+__global__ __launch_bounds__(ROUNDS_PER_LAUNCH) void k_geo_count(const GeoPair* __restrict__ pairs, uint32_t first_round) {
+#pragma clang fp contract(off)
+  __shared__ double2 tile_l[COUNT_TILE], tile_r[COUNT_TILE];
+  const GeoPair P = pairs[blockIdx.x];
+  const GeoState* st = P.state;
+  if (st->done) return;
+  const uint32_t slot = threadIdx.x;
+  const bool live = first_round + slot < st->rounds_limit;   // the same rounds k_geo_fit worked on
+  const int n = P.n;
+  double F[9];
+  int idx[SAMPLE];
+#pragma unroll
+  for (int k = 0; k < 9; k++) F[k] = live ? P.hyp_F[(size_t)slot * 9 + k] : 0.0;
+#pragma unroll
+  for (int k = 0; k < SAMPLE; k++) idx[k] = live ? P.hyp_idx[(size_t)slot * SAMPLE + k] : -1;
+  // ransac.hpp:112-124: the sample is in unexamined, everything else unless its error exceeds 3.84
+  uint32_t count = SAMPLE;
+  for (int i0 = 0; i0 < n; i0 += COUNT_TILE) {
+    const int m = min(COUNT_TILE, n - i0);
+    if ((int)threadIdx.x < m) {
+      tile_l[threadIdx.x] = reinterpret_cast<const double2*>(P.lhs)[i0 + threadIdx.x];
+      tile_r[threadIdx.x] = reinterpret_cast<const double2*>(P.rhs)[i0 + threadIdx.x];
+    }
+    __syncthreads();
+    if (live) {
+      for (int t = 0; t < m; t++) {
+        const double2 a = tile_l[t], b = tile_r[t];
+        const int i = i0 + t;
+        bool in_sample = false;
+#pragma unroll
+        for (int k = 0; k < SAMPLE; k++) in_sample |= idx[k] == i;
+        const double err = epipolar_line_error(a.x, a.y, b.x, b.y, F);
+        count += (!in_sample && !(err > 3.84)) ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+  }
+  if (live) P.hyp_count[slot] = count;
 }
 
 // ---------------------------------------------------------------------------------------------

