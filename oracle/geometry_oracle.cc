@@ -29,7 +29,6 @@
 #include <cstdint>
 #include <cstring>
 #include <random>
-#include <set>
 #include <vector>
 
 namespace {

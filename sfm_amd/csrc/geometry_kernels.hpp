@@ -296,7 +296,7 @@ __global__ __launch_bounds__(ROUNDS_PER_LAUNCH) void k_geo_count(const GeoPair* 
 // ---------------------------------------------------------------------------------------------
 // ransac.hpp:126-142 over the launch's results in round order.  One thread per pair.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restrict__ pairs, int n_pairs, uint32_t first_round,
+__global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restrict__ pairs, int n_pairs,
                                                         uint32_t* __restrict__ unfinished) {
   const int p = blockIdx.x * 64 + threadIdx.x;
   if (p >= n_pairs) return;
@@ -330,7 +330,6 @@ __global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restric
   st->best_count = best;
   st->done = finished ? 1u : 0u;
   if (!finished) atomicAdd(unfinished, 1u);
-  (void)first_round;
 }
 
 // ---------------------------------------------------------------------------------------------

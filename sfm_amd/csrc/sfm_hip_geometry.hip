@@ -146,7 +146,7 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_geo_count, dim3((unsigned)n_live), dim3(ROUNDS_PER_LAUNCH), 0, st, dp, first);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)((n_live + 63) / 64)), dim3(64), 0, st, dp, n_live, first,
+    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)((n_live + 63) / 64)), dim3(64), 0, st, dp, n_live,
                        (uint32_t*)d_unfinished.p);
     HIP_TRY(ctx, hipGetLastError());
     uint32_t unfinished = 0;
