@@ -29,6 +29,10 @@ def lib():
         vp, i64 = ctypes.c_void_p, ctypes.c_int64
         l.ch_set_projection.argtypes = [vp, vp]
         l.ch_set_projection.restype = None
+        l.ch_l2_metric.argtypes = [vp, vp]
+        l.ch_l2_metric.restype = ctypes.c_float
+        l.ch_hamming.argtypes = [vp, vp]
+        l.ch_hamming.restype = ctypes.c_int
         l.ch_projection.argtypes = [vp, vp]
         l.ch_projection.restype = None
         l.ch_image_order.argtypes = [vp, i64, vp]

@@ -238,6 +238,18 @@ int64_t ch_image_order(const int64_t* pair_ids, int64_t n_pairs, int64_t* out_id
   return n;
 }
 
+// The two measures the matching uses, as this oracle computes them (tests compare them with the
+// reference's own src/metric.hpp built from the reference checkout).
+float ch_l2_metric(const float* lhs, const float* rhs) { return l2_metric(lhs, rhs); }
+int ch_hamming(const uint32_t* lhs, const uint32_t* rhs) {
+  std::bitset<128> a, b;
+  for (int j = 0; j < 128; j++) {
+    a[(size_t)j] = (lhs[j / 32] >> (j % 32)) & 1u;
+    b[(size_t)j] = (rhs[j / 32] >> (j % 32)) & 1u;
+  }
+  return (int)(a ^ b).count();
+}
+
 void ch_image_column_sums(const float* raw, int64_t n, float* out128) { image_column_sums(raw, n, out128); }
 
 // cascade_hash_matcher.cc:154-165: images in the order given (ch_image_order)

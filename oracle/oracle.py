@@ -83,6 +83,9 @@ def ref_metric_lib():
     r = ctypes.CDLL(_REF)
     r.ref_L2_metric.restype = ctypes.c_float
     r.ref_L2_metric.argtypes = [_f32p, _f32p]
+    if hasattr(r, "ref_HammingDistance128"):
+        r.ref_HammingDistance128.restype = ctypes.c_int
+        r.ref_HammingDistance128.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     return r
 
 

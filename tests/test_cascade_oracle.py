@@ -241,3 +241,34 @@ def test_golden_cases_reproduce():
     for c, w in zip(g.CASCADE_CASES, want["cases"]):
         assert g.cascade_case(c) == w, c[0]
     assert sum(pr["count"] for w in want["cases"] for pr in w["pairs"]) > 300
+
+
+def test_measures_equal_the_reference_build_bit_for_bit():
+    """The two measures the cascade matcher uses -- L2_metric and HammingDistance, both in the
+    reference's src/metric.hpp -- against that header compiled from the reference checkout
+    (oracle/_ref, built by oracle/Makefile).  This is the part of this matcher that IS pinned."""
+    import ctypes
+    from oracle import oracle
+    ref = oracle.ref_metric_lib()
+    if ref is None or not hasattr(ref, "ref_HammingDistance128"):
+        pytest.skip("oracle/_ref was not built (no reference checkout on this machine)")
+    lib = cascade.lib()
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 2 ** 32, size=(300, 4), dtype=np.uint64).astype(np.uint32)
+    other = base.copy()
+    for r in range(300):           # from identical to unrelated
+        flips = rng.integers(0, 128, size=r % 40)
+        for f in flips:
+            other[r, f // 32] ^= np.uint32(1 << (f % 32))
+    other[200:] = rng.integers(0, 2 ** 32, size=(100, 4), dtype=np.uint64).astype(np.uint32)
+    for a, b in zip(base, other):
+        want = ref.ref_HammingDistance128(a.ctypes.data, b.ctypes.data)
+        assert lib.ch_hamming(a.ctypes.data, b.ctypes.data) == want
+        assert want == sum(bin(int(x) ^ int(y)).count("1") for x, y in zip(a, b))
+    rows = synth.rootsift_rows(200, 5)
+    fp = ctypes.POINTER(ctypes.c_float)
+    for k in range(100):
+        a, b = rows[k], rows[199 - k]
+        want = np.float32(ref.ref_L2_metric(a.ctypes.data_as(fp), b.ctypes.data_as(fp)))
+        got = np.float32(lib.ch_l2_metric(a.ctypes.data, b.ctypes.data))
+        assert got.view(np.uint32) == want.view(np.uint32)
