@@ -169,9 +169,10 @@ typedef struct {
   uint64_t match_launches;  /* batches of sfm_hip_cascade_match_pairs that were timed */
   double match_ms;          /* their summed duration on the GPU, first kernel to last (HIP events on
                                the stream they run on; only while profiling is enabled) */
-  double match_bytes;       /* bytes those batches had to read at the least: per pair the bucket-ordered
-                               hash records of both images once (6 groups x 32 bytes per descriptor)
-                               and one 16-byte result word per descriptor */
+  double match_bytes;       /* bytes those batches had to read at the least: per pair and bucket group the
+                               low halves of both images' hash codes in bucket order (8 bytes per
+                               descriptor) and the first image's bucket ids (2 bytes), plus one 16-byte
+                               result word per descriptor */
   uint64_t list_overflows;  /* pairs with more close candidate pairs than their list holds, matched by
                                the slower path that needs no list */
   uint64_t workspace_dirty_words; /* non-zero words found in the per-query work space, which every

@@ -88,20 +88,28 @@ struct ImageRef {
 struct HashJob {
   const float* d;        // [n][128]
   HashRec* recs;         // [n]
-  uint4* gcodes;         // [6][n] hash codes in group g's bucket order
-  HashMeta* gmeta;       // [6][n] bucket ids and index, same order
+  uint2* glo;            // [6][n] low 64 bits of the hash codes in group g's bucket order
+  uint2* ghi;            // [6][n] high 64 bits, same order
+  uint16_t* gbkt;        // [6][n] group g's bucket id, same order
+  HashMeta* gmeta;       // [6][n] all bucket ids and the index, same order
   int32_t* offsets;      // [6][1025]
   int32_t n;
   int32_t first_block;   // k_ch_hash: the job's first workgroup in the launch
 };
 
 struct CascadePair {
-  const uint4* ca;       // first image: codes in bucket order, [6][na]
-  const HashMeta* ma;    //              bucket ids + index, [6][na]
-  const uint4* cb;       // second image
-  const HashMeta* mb;
-  const int32_t* offa;   // bucket offsets [6][1025]
-  const int32_t* offb;
+  // first image, per group in that group's bucket order ([6][na] each): the low halves of the codes
+  // and the group's bucket id are what every record of the walk reads; the high halves and the full
+  // bucket ids + index only for the few candidates that pass the first test
+  const uint2* a_lo;
+  const uint2* a_hi;
+  const uint16_t* a_bkt;
+  const HashMeta* a_meta;
+  // second image ([6][nb] each)
+  const uint2* b_lo;
+  const uint2* b_hi;
+  const HashMeta* b_meta;
+  const int32_t* offb;   // second image: bucket offsets [6][1025]
   const float* da;       // descriptor rows
   const float* db;
   uint32_t* hist_a;      // [na][12]
@@ -113,6 +121,7 @@ struct CascadePair {
   uint32_t* overflow;    // non-zero: some segment was too small, the list is incomplete (zero between batches)
   int32_t na, nb;
   int32_t out_slot;
+  int32_t pad_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -274,7 +283,9 @@ __global__ __launch_bounds__(64) void k_ch_group(const HashJob* __restrict__ job
   }
   if (lane == 63) off[BUCKETS] = n;
   __syncthreads();
-  uint4* out_codes = job.gcodes + (size_t)g * (size_t)n;
+  uint2* out_lo = job.glo + (size_t)g * (size_t)n;
+  uint2* out_hi = job.ghi + (size_t)g * (size_t)n;
+  uint16_t* out_bkt = job.gbkt + (size_t)g * (size_t)n;
   HashMeta* out_meta = job.gmeta + (size_t)g * (size_t)n;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
@@ -287,7 +298,9 @@ __global__ __launch_bounds__(64) void k_ch_group(const HashJob* __restrict__ job
     if (valid) pos = cur[b] + __popcll(same & below);
     __syncthreads();
     if (valid) {
-      out_codes[pos] = make_uint4(rec.code[0], rec.code[1], rec.code[2], rec.code[3]);
+      out_lo[pos] = make_uint2(rec.code[0], rec.code[1]);
+      out_hi[pos] = make_uint2(rec.code[2], rec.code[3]);
+      out_bkt[pos] = (uint16_t)b;
       HashMeta m;
       m.bids[0] = rec.bids[0];
       m.bids[1] = rec.bids[1];
@@ -358,9 +371,12 @@ __device__ __forceinline__ void fold_distance(const CascadePair& P, uint32_t i, 
 // first image in group g's bucket order, one per thread; the buckets they sit in are consecutive,
 // so the records of the second image they have to meet form ONE contiguous run, which the
 // workgroup stages in LDS, and every thread scans the part of it that is its own bucket.
-// The scan is bound by instruction issue, so it looks at the low 64 bits of the hash codes first,
-// two candidates per step: two codes that differ in more than ten of those bits (practically every
-// candidate) are done after two XORs and two population counts each.
+// The walk is bound by the bytes it streams (its two loading phases run at 6-8 TB/s), so it streams
+// as few as it can: per record of either image only the low 64 bits of the hash code, plus two
+// bytes of bucket id on the first image's side.  Two codes that differ in more than ten of those
+// 64 bits (practically every candidate) are done after two XORs and two population counts; the
+// candidates that pass are queued per wavefront and finished afterwards with every lane busy, from
+// the high halves, bucket ids and indices in memory.
 // The close pairs found go to a segment of the pair's list that belongs to this workgroup alone:
 // nothing is reserved through an atomic and nothing waits for one.
 // A pair that shares buckets in several groups is handled in the lowest such group only: that is
@@ -376,25 +392,65 @@ constexpr int WALK_THREADS = 256;
 constexpr int WALK_CHUNK = 512;      // staged records of the second image per step
 constexpr int LIST_SEGMENT = 128;    // close pairs a workgroup can report
 
+constexpr int WALK_QUEUE = 256;      // candidates per wavefront and staged chunk that pass the first test
+
 struct WalkShared {
   uint2 lo[WALK_CHUNK + 2];     // low halves of the staged codes (+2: the scan reads in twos)
-  uint2 hi[WALK_CHUNK];
-  HashMeta meta[WALK_CHUNK];
   uint2 found[LIST_SEGMENT];
+  uint32_t queue[WALK_THREADS / 64][WALK_QUEUE];   // per wavefront: owner lane << 16 | staged index
   int range[2];
   uint32_t n_found;
 };
+
+// Second half of the scan for the queued candidates of one wavefront: entry k goes to lane k % 64,
+// which takes the low half of the first-image code from the lane that owns the record and reads
+// the rest of both records (high halves, bucket ids, indices) from memory -- 64 candidates per
+// round trip, where a lane finishing its own on the spot would hold up its 63 neighbours.
+// a_at: position of lane 0's record in the first image's bucket order; b_at: of staged index 0.
+template <int MODE>
+__device__ __forceinline__ void finish_queue(const CascadePair& P, int g, int both_directions, WalkShared& sh,
+                                             const uint32_t* queue, uint32_t count, uint2 lo, size_t a_at, size_t b_at) {
+  const int lane = threadIdx.x & 63;
+  for (uint32_t k0 = 0; k0 < count; k0 += 64) {    // count is the same in every lane
+    const uint32_t k = k0 + lane;
+    const bool mine = k < count;
+    const uint32_t entry = mine ? queue[k] : 0u;
+    const int owner = (int)(entry >> 16), r = (int)(entry & 0xFFFFu);
+    const uint32_t alx = __shfl(lo.x, owner), aly = __shfl(lo.y, owner);
+    if (!mine) continue;
+    const uint2 ah = P.a_hi[a_at + owner], bh = P.b_hi[b_at + r];
+    const uint2 bl = sh.lo[r];
+    const uint32_t h = __popc(alx ^ bl.x) + __popc(aly ^ bl.y) + __popc(ah.x ^ bh.x) + __popc(ah.y ^ bh.y);
+    if (h > (uint32_t)MAX_HAMMING) continue;
+    const HashMeta ma = P.a_meta[a_at + owner], other = P.b_meta[b_at + r];
+    const uint32_t x0 = ma.bids[0] ^ other.bids[0], x1 = ma.bids[1] ^ other.bids[1], x2 = ma.bids[2] ^ other.bids[2];
+    bool earlier = false;   // shares a bucket in a group before g: counted there
+    if (g > 0) earlier |= (x0 & 0xFFFFu) == 0;
+    if (g > 1) earlier |= (x0 >> 16) == 0;
+    if (g > 2) earlier |= (x1 & 0xFFFFu) == 0;
+    if (g > 3) earlier |= (x1 >> 16) == 0;
+    if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
+    if (earlier) continue;
+    const uint32_t i = ma.idx, j = other.idx;
+    if (MODE == WALK_COUNT) {
+      atomicAdd(P.hist_a + (size_t)i * HIST_WORDS + h, 1u);
+      if (both_directions) atomicAdd(P.hist_b + (size_t)j * HIST_WORDS + h, 1u);
+      const uint32_t at = atomicAdd(&sh.n_found, 1u);
+      if (at < (uint32_t)LIST_SEGMENT) sh.found[at] = make_uint2(i, j | (h << LIST_H_SHIFT));
+    } else {
+      const bool fa = inside_taken_bins(P.res_a[(size_t)i * RES_WORDS + RES_STATE], h);
+      const bool fb = both_directions && inside_taken_bins(P.res_b[(size_t)j * RES_WORDS + RES_STATE], h);
+      if (fa || fb) fold_distance(P, i, j, fa, fb);
+    }
+  }
+}
 
 // The work of workgroup bx of nbx for (pair P, group g).
 template <int MODE>
 __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, int nbx, int both_directions,
                                            WalkShared& sh) {
   uint2* stage_lo = sh.lo;
-  uint2* stage_hi = sh.hi;
-  HashMeta* stage_meta = sh.meta;
-  uint2* found = sh.found;
   int* range = sh.range;
-  uint32_t& n_found = sh.n_found;
   const int na = P.na, nb = P.nb;
   const int tid = threadIdx.x;
   const int p0 = bx * WALK_THREADS;
@@ -403,86 +459,65 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
     if (MODE == WALK_COUNT && tid == 0) P.seg_counts[seg] = 0;
     return;
   }
-  const uint4* cb = P.cb + (size_t)g * (size_t)nb;
-  const HashMeta* mb = P.mb + (size_t)g * (size_t)nb;
+  const size_t a_group = (size_t)g * (size_t)na, b_group = (size_t)g * (size_t)nb;
+  const uint2* b_lo = P.b_lo + b_group;
   const int32_t* off = P.offb + (size_t)g * (BUCKETS + 1);
   const int p = p0 + tid;
   const bool valid = p < na;
-  uint4 code = make_uint4(0, 0, 0, 0);
-  HashMeta meta{};
+  uint2 lo_half = make_uint2(0, 0);
   int s = 0, e = 0;
   if (valid) {
-    code = P.ca[(size_t)g * (size_t)na + p];
-    meta = P.ma[(size_t)g * (size_t)na + p];
-    const uint32_t b = (meta.bids[g >> 1] >> ((g & 1) * 16)) & 0xFFFFu;
+    lo_half = P.a_lo[a_group + p];
+    const uint32_t b = P.a_bkt[a_group + p];
     s = off[b];
     e = off[b + 1];
   }
   if (tid == 0) {
     range[0] = s;
-    n_found = 0;
+    sh.n_found = 0;
   }
   if (p == min(p0 + WALK_THREADS - 1, na - 1)) range[1] = e;
   __syncthreads();
   const int lo = range[0], hi = range[1];
+  uint32_t* queue = sh.queue[tid >> 6];
+  const int lane = tid & 63;
+  const unsigned long long below = ((unsigned long long)1 << lane) - 1;
+  const size_t a_at = a_group + (size_t)(p0 + (tid & ~63));   // lane 0's record
   for (int c0 = lo; c0 < hi; c0 += WALK_CHUNK) {
     const int cnt = min(WALK_CHUNK, hi - c0);
-    for (int r = tid; r < cnt; r += WALK_THREADS) {
-      const uint4 c = cb[c0 + r];
-      stage_lo[r] = make_uint2(c.x, c.y);
-      stage_hi[r] = make_uint2(c.z, c.w);
-      stage_meta[r] = mb[c0 + r];
-    }
+    for (int r = tid; r < cnt; r += WALK_THREADS) stage_lo[r] = b_lo[c0 + r];
     __syncthreads();
-#ifdef SFM_ABLATE_WALK_LOOP   // timing experiments only (tools/build_variant.sh)
-    const int q1 = 0;
-#else
+    // First test, every candidate: the low 64 bits, two candidates per step.  The few that pass
+    // are queued per wavefront (ballot, no atomics) and finished afterwards with every lane busy.
     const int q1 = min(e, c0 + cnt);
-#endif
-    for (int q = max(s, c0); q < q1; q += 2) {
-      const uint2 t0 = stage_lo[q - c0], t1 = stage_lo[q - c0 + 1];
-      const uint32_t l0 = __popc(code.x ^ t0.x) + __popc(code.y ^ t0.y);
-      const uint32_t l1 = q + 1 < q1 ? __popc(code.x ^ t1.x) + __popc(code.y ^ t1.y) : 99u;
-      if (min(l0, l1) > (uint32_t)MAX_HAMMING) continue;
-      for (int k = 0; k < 2; k++) {
-        const uint32_t low = k ? l1 : l0;
-        if (low > (uint32_t)MAX_HAMMING) continue;
-        const int r = q - c0 + k;
-        const uint2 th = stage_hi[r];
-        const uint32_t h = low + __popc(code.z ^ th.x) + __popc(code.w ^ th.y);
-        if (h > (uint32_t)MAX_HAMMING) continue;
-        const HashMeta other = stage_meta[r];
-        const uint32_t x0 = meta.bids[0] ^ other.bids[0], x1 = meta.bids[1] ^ other.bids[1], x2 = meta.bids[2] ^ other.bids[2];
-        bool earlier = false;   // shares a bucket in a group before g: counted there
-        if (g > 0) earlier |= (x0 & 0xFFFFu) == 0;
-        if (g > 1) earlier |= (x0 >> 16) == 0;
-        if (g > 2) earlier |= (x1 & 0xFFFFu) == 0;
-        if (g > 3) earlier |= (x1 >> 16) == 0;
-        if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
-        if (earlier) continue;
-        const uint32_t i = meta.idx, j = other.idx;
-        if (MODE == WALK_COUNT) {
-#ifndef SFM_ABLATE_WALK_HIST
-          atomicAdd(P.hist_a + (size_t)i * HIST_WORDS + h, 1u);
-          if (both_directions) atomicAdd(P.hist_b + (size_t)j * HIST_WORDS + h, 1u);
-#endif
-          const uint32_t at = atomicAdd(&n_found, 1u);
-          if (at < (uint32_t)LIST_SEGMENT) found[at] = make_uint2(i, j | (h << LIST_H_SHIFT));
-        } else {
-          const bool fa = inside_taken_bins(P.res_a[(size_t)i * RES_WORDS + RES_STATE], h);
-          const bool fb = both_directions && inside_taken_bins(P.res_b[(size_t)j * RES_WORDS + RES_STATE], h);
-          if (fa || fb) fold_distance(P, i, j, fa, fb);
-        }
+    uint32_t queued = 0;     // the same in every lane of the wavefront
+    for (int q = max(s, c0); __any(q < q1); q += 2) {
+      const bool live = q < q1;
+      const int r = live ? q - c0 : 0;
+      const uint2 t0 = stage_lo[r], t1 = stage_lo[r + 1];
+      const bool hit0 = live && __popc(lo_half.x ^ t0.x) + __popc(lo_half.y ^ t0.y) <= (uint32_t)MAX_HAMMING;
+      const bool hit1 = live && q + 1 < q1 && __popc(lo_half.x ^ t1.x) + __popc(lo_half.y ^ t1.y) <= (uint32_t)MAX_HAMMING;
+      const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+      if ((m0 | m1) == 0) continue;
+      const uint32_t at0 = queued + __popcll(m0 & below);
+      const uint32_t at1 = queued + __popcll(m0) + __popcll(m1 & below);
+      if (hit0) queue[at0] = ((uint32_t)lane << 16) | (uint32_t)r;
+      if (hit1) queue[at1] = ((uint32_t)lane << 16) | (uint32_t)(r + 1);
+      queued += __popcll(m0) + __popcll(m1);
+      if (queued > (uint32_t)WALK_QUEUE - 128) {     // the next step might not fit: finish these now
+        finish_queue<MODE>(P, g, both_directions, sh, queue, queued, lo_half, a_at, b_group + (size_t)c0);
+        queued = 0;
       }
     }
+    finish_queue<MODE>(P, g, both_directions, sh, queue, queued, lo_half, a_at, b_group + (size_t)c0);
     __syncthreads();
   }
   if (MODE == WALK_COUNT) {
     // no round trip here: the segment is this workgroup's own
-    const uint32_t total = n_found;
+    const uint32_t total = sh.n_found;
     const uint32_t mine = min(total, (uint32_t)LIST_SEGMENT);
     uint2* out = P.list + (size_t)seg * LIST_SEGMENT;
-    for (uint32_t k = tid; k < mine; k += WALK_THREADS) out[k] = found[k];
+    for (uint32_t k = tid; k < mine; k += WALK_THREADS) out[k] = sh.found[k];
     if (tid == 0) {
       P.seg_counts[seg] = mine;
       if (total > (uint32_t)LIST_SEGMENT) *P.overflow = 1;

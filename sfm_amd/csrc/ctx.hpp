@@ -25,8 +25,11 @@ struct Image {
   // image order, the six copies sorted by bucket, and the bucket offsets
   void* hash_block = nullptr;
   void* hash_recs = nullptr;      // [n] records of 32 bytes, image order
-  void* hash_gcodes = nullptr;    // [6][n] hash codes, group g sorted by its bucket id, then by index
-  void* hash_gmeta = nullptr;     // [6][n] bucket ids + index, same order
+  // per group, sorted by that group's bucket id, then by index ([6][n] each):
+  void* hash_glo = nullptr;       // low 64 bits of the codes
+  void* hash_ghi = nullptr;       // high 64 bits
+  void* hash_gbkt = nullptr;      // the group's bucket id (16 bits)
+  void* hash_gmeta = nullptr;     // all bucket ids + index
   int32_t* hash_offsets = nullptr;  // [6][1025]
 };
 
@@ -148,7 +151,9 @@ inline void free_image_hashes(Image& im) {
   if (im.hash_block) (void)hipFree(im.hash_block);
   im.hash_block = nullptr;
   im.hash_recs = nullptr;
-  im.hash_gcodes = nullptr;
+  im.hash_glo = nullptr;
+  im.hash_ghi = nullptr;
+  im.hash_gbkt = nullptr;
   im.hash_gmeta = nullptr;
   im.hash_offsets = nullptr;
 }

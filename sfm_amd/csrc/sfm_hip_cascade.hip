@@ -142,22 +142,33 @@ int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
     if (n > (size_t)MAX_IMAGE_ROWS)
       return fail(ctx, SFM_HIP_ERR_INVALID, "the cascade-hash path takes images of at most 262,144 descriptors");
     const size_t recs_bytes = align_up(std::max<size_t>(n, 1) * sizeof(HashRec), 256);
-    const size_t codes_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(uint4), 256);
+    const size_t half_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(uint2), 256);
+    const size_t bkt_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(uint16_t), 256);
     const size_t meta_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(HashMeta), 256);
     const size_t off_bytes = align_up((size_t)GROUPS * (BUCKETS + 1) * sizeof(int32_t), 256);
-    hipError_t e = hipMalloc(&im->hash_block, recs_bytes + codes_bytes + meta_bytes + off_bytes);
+    hipError_t e = hipMalloc(&im->hash_block, recs_bytes + 2 * half_bytes + bkt_bytes + meta_bytes + off_bytes);
     if (e != hipSuccess) {
       im->hash_block = nullptr;
       return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc hash records: ") + hipGetErrorString(e));
     }
-    im->hash_recs = im->hash_block;
-    im->hash_gcodes = (char*)im->hash_block + recs_bytes;
-    im->hash_gmeta = (char*)im->hash_block + recs_bytes + codes_bytes;
-    im->hash_offsets = (int32_t*)((char*)im->hash_block + recs_bytes + codes_bytes + meta_bytes);
+    char* at = (char*)im->hash_block;
+    im->hash_recs = at;
+    at += recs_bytes;
+    im->hash_glo = at;
+    at += half_bytes;
+    im->hash_ghi = at;
+    at += half_bytes;
+    im->hash_gbkt = at;
+    at += bkt_bytes;
+    im->hash_gmeta = at;
+    at += meta_bytes;
+    im->hash_offsets = (int32_t*)at;
     HashJob j;
     j.d = im->d;
     j.recs = (HashRec*)im->hash_recs;
-    j.gcodes = (uint4*)im->hash_gcodes;
+    j.glo = (uint2*)im->hash_glo;
+    j.ghi = (uint2*)im->hash_ghi;
+    j.gbkt = (uint16_t*)im->hash_gbkt;
     j.gmeta = (HashMeta*)im->hash_gmeta;
     j.offsets = im->hash_offsets;
     j.n = im->n;
@@ -305,11 +316,13 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       const Image& X = *plan[(size_t)(done + k)].first;
       const Image& Y = *plan[(size_t)(done + k)].second;
       CascadePair& d = hp[k];
-      d.ca = (const uint4*)X.hash_gcodes;
-      d.ma = (const HashMeta*)X.hash_gmeta;
-      d.cb = (const uint4*)Y.hash_gcodes;
-      d.mb = (const HashMeta*)Y.hash_gmeta;
-      d.offa = X.hash_offsets;
+      d.a_lo = (const uint2*)X.hash_glo;
+      d.a_hi = (const uint2*)X.hash_ghi;
+      d.a_bkt = (const uint16_t*)X.hash_gbkt;
+      d.a_meta = (const HashMeta*)X.hash_gmeta;
+      d.b_lo = (const uint2*)Y.hash_glo;
+      d.b_hi = (const uint2*)Y.hash_ghi;
+      d.b_meta = (const HashMeta*)Y.hash_gmeta;
       d.offb = Y.hash_offsets;
       d.da = X.d;
       d.db = Y.d;
@@ -327,11 +340,14 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       d.na = X.n;
       d.nb = Y.n;
       d.out_slot = k;
+      d.pad_ = 0;
       max_na = std::max(max_na, X.n);
       max_n = std::max(max_n, std::max(X.n, cross_check ? Y.n : 0));
-      // what one pair has to read at the least: both images' bucket-ordered records (code, bucket
-      // ids and index: 32 bytes) in all six groups, and one 16-byte result word per descriptor
-      bytes += GROUPS * ((double)X.n + (double)Y.n) * (sizeof(uint4) + sizeof(HashMeta)) + 16.0 * ((double)X.n + (double)Y.n);
+      // what one pair has to read at the least: in all six groups the low halves of both images'
+      // bucket-ordered codes (8 bytes) and the first image's bucket ids (2 bytes), and one 16-byte
+      // result word per descriptor
+      bytes += GROUPS * ((double)X.n * (sizeof(uint2) + sizeof(uint16_t)) + (double)Y.n * sizeof(uint2)) +
+               16.0 * ((double)X.n + (double)Y.n);
     }
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->profiling) {
