@@ -418,10 +418,8 @@ __device__ __forceinline__ void finish_queue(const CascadePair& P, int g, int bo
     const int owner = (int)(entry >> 16), r = (int)(entry & 0xFFFFu);
     const uint32_t alx = __shfl(lo.x, owner), aly = __shfl(lo.y, owner);
     if (!mine) continue;
-    const uint2 ah = P.a_hi[a_at + owner], bh = P.b_hi[b_at + r];
-    const uint2 bl = sh.lo[r];
-    const uint32_t h = __popc(alx ^ bl.x) + __popc(aly ^ bl.y) + __popc(ah.x ^ bh.x) + __popc(ah.y ^ bh.y);
-    if (h > (uint32_t)MAX_HAMMING) continue;
+    // the bucket ids first: a pair of near-duplicates shares most of its six buckets and is dropped
+    // here in all groups but the lowest, before its codes are fetched
     const HashMeta ma = P.a_meta[a_at + owner], other = P.b_meta[b_at + r];
     const uint32_t x0 = ma.bids[0] ^ other.bids[0], x1 = ma.bids[1] ^ other.bids[1], x2 = ma.bids[2] ^ other.bids[2];
     bool earlier = false;   // shares a bucket in a group before g: counted there
@@ -431,6 +429,10 @@ __device__ __forceinline__ void finish_queue(const CascadePair& P, int g, int bo
     if (g > 3) earlier |= (x1 >> 16) == 0;
     if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
     if (earlier) continue;
+    const uint2 ah = P.a_hi[a_at + owner], bh = P.b_hi[b_at + r];
+    const uint2 bl = sh.lo[r];
+    const uint32_t h = __popc(alx ^ bl.x) + __popc(aly ^ bl.y) + __popc(ah.x ^ bh.x) + __popc(ah.y ^ bh.y);
+    if (h > (uint32_t)MAX_HAMMING) continue;
     const uint32_t i = ma.idx, j = other.idx;
     if (MODE == WALK_COUNT) {
       atomicAdd(P.hist_a + (size_t)i * HIST_WORDS + h, 1u);
@@ -478,7 +480,11 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
   }
   if (p == min(p0 + WALK_THREADS - 1, na - 1)) range[1] = e;
   __syncthreads();
+#if defined(SFM_ABLATE_WALK_UPTO) && SFM_ABLATE_WALK_UPTO <= 1   // timing experiments only (tools/build_variant.sh)
+  const int lo = 0, hi = lo_half.x == 0x12345678u ? range[1] : 0;
+#else
   const int lo = range[0], hi = range[1];
+#endif
   uint32_t* queue = sh.queue[tid >> 6];
   const int lane = tid & 63;
   const unsigned long long below = ((unsigned long long)1 << lane) - 1;
@@ -489,7 +495,11 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
     __syncthreads();
     // First test, every candidate: the low 64 bits, two candidates per step.  The few that pass
     // are queued per wavefront (ballot, no atomics) and finished afterwards with every lane busy.
+#if defined(SFM_ABLATE_WALK_UPTO) && SFM_ABLATE_WALK_UPTO <= 2   // timing experiments only
+    const int q1 = stage_lo[tid].x == 0x12345678u ? e : 0;
+#else
     const int q1 = min(e, c0 + cnt);
+#endif
     uint32_t queued = 0;     // the same in every lane of the wavefront
     for (int q = max(s, c0); __any(q < q1); q += 2) {
       const bool live = q < q1;
@@ -497,8 +507,12 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
       const uint2 t0 = stage_lo[r], t1 = stage_lo[r + 1];
       const bool hit0 = live && __popc(lo_half.x ^ t0.x) + __popc(lo_half.y ^ t0.y) <= (uint32_t)MAX_HAMMING;
       const bool hit1 = live && q + 1 < q1 && __popc(lo_half.x ^ t1.x) + __popc(lo_half.y ^ t1.y) <= (uint32_t)MAX_HAMMING;
+#if defined(SFM_ABLATE_WALK_UPTO) && SFM_ABLATE_WALK_UPTO <= 3   // timing experiments only
+      if (!__any((hit0 || hit1) && t0.x == 0x12345678u)) continue;
+#else
+      if (!__any(hit0 || hit1)) continue;
+#endif
       const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-      if ((m0 | m1) == 0) continue;
       const uint32_t at0 = queued + __popcll(m0 & below);
       const uint32_t at1 = queued + __popcll(m0) + __popcll(m1 & below);
       if (hit0) queue[at0] = ((uint32_t)lane << 16) | (uint32_t)r;

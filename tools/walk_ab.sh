@@ -1,3 +1,7 @@
+#!/bin/bash
+# Runs on the GPU box: kernel statistics of the bucket walk for library variants built by
+# tools/build_variant.sh with -DSFM_ABLATE_WALK_UPTO=1..3 (a1: first-image loads and offsets only;
+# a2: + staging of the second image's run; a3: + the scan without its hits; a4: everything).
 cd /tmp && export TMPDIR=/tmp
 for v in a1 a2 a3 a4; do
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/cprof_$v
