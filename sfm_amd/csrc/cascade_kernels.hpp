@@ -4,8 +4,10 @@
 // Per image, once (ConstructHashDescriptors, .cc:11-49):
 //   k_ch_colsum   the image's share of the mean vector (.cc:160-162)
 //   k_ch_hash     188 projections of every centred descriptor -> 128-bit code + six 10-bit bucket ids
-//   k_ch_group    per group a copy of the hash records sorted by bucket (stable: ascending index
-//                 inside a bucket, the order .cc:43-46 fills them in) + bucket offsets
+//   k_ch_group    per group the hash records sorted by bucket (stable: ascending index inside a
+//                 bucket, the order .cc:43-46 fills them in), laid out as four arrays -- low halves
+//                 of the codes, high halves, the group's own bucket id, all bucket ids + index --
+//                 + bucket offsets
 // Per pair (DescriptorMath both ways + cross-check, .cc:51-116, :173-195):
 //   k_ch_walk_count      walk every (first-image descriptor, second-image descriptor) that share a
 //                        bucket; those within Hamming distance 10 ("close pairs") are counted into
