@@ -48,7 +48,7 @@ void materialise(PairJob& job, int32_t n_default, const int32_t* lhs, const int3
 // need any image), hashes, then this GPU's slice of the pair list in batches.  Two sets of pinned
 // result buffers alternate: the GPU matches batch b while this thread builds batch b-1's records.
 void run_device(int device, const SfMData& scene, const std::vector<int64_t>& flat_pairs, std::vector<PairJob>& jobs,
-                size_t lo, size_t hi, bool cross) {
+                size_t lo, size_t hi, bool cross, int helpers) {
   sfm_hip_ctx* ctx = nullptr;
   if (sfm_hip_ctx_create(device, &ctx) != SFM_HIP_OK) fail(nullptr, "sfm_hip_ctx_create");
   struct Guard {
@@ -94,10 +94,33 @@ void run_device(int device, const SfMData& scene, const std::vector<int64_t>& fl
                                     s.lhs, s.rhs, nullptr, stride) != SFM_HIP_OK)
       fail(ctx, "sfm_hip_cascade_match_pairs");
   };
+  // Building the records is the bulk of the host's work (48 bytes each, observations looked up per
+  // index) and every pair's list is independent: a few helper threads share a batch's pairs.
   auto collect = [&](size_t b0, const Set& s) {
     const size_t n = std::min(batch, hi - b0);
-    for (size_t k = 0; k < n; k++)
-      materialise(jobs[b0 + k], s.defaults[k], s.lhs + k * stride, s.rhs + k * stride, s.counts[k]);
+    const size_t n_helpers = std::min<size_t>((size_t)helpers, n);
+    auto part = [&](size_t t) {
+      for (size_t k = t; k < n; k += n_helpers)
+        materialise(jobs[b0 + k], s.defaults[k], s.lhs + k * stride, s.rhs + k * stride, s.counts[k]);
+    };
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> failed(n_helpers);
+    for (size_t t = 1; t < n_helpers; t++)
+      pool.emplace_back([&, t] {
+        try {
+          part(t);
+        } catch (...) {
+          failed[t] = std::current_exception();
+        }
+      });
+    try {
+      part(0);
+    } catch (...) {
+      failed[0] = std::current_exception();
+    }
+    for (auto& th : pool) th.join();
+    for (auto& f : failed)
+      if (f) std::rethrow_exception(f);
   };
   size_t which = 0, prev = lo;
   submit(lo, sets[which]);
@@ -147,6 +170,9 @@ void HipCascadeHashMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs
   const char* over = std::getenv("SFM_HIP_OVERSUBSCRIBE");   // more shards than GPUs, for testing
   const bool oversubscribe = over && std::string(over) == "1";
   const int n_dev = (int)std::min<size_t>((size_t)(oversubscribe ? want : std::min(want, visible)), jobs.size());
+  // host threads that turn index lists into Match records, per GPU
+  const unsigned cores = std::thread::hardware_concurrency();
+  const int helpers = (int)std::max(1u, std::min(8u, (cores ? cores : 8u) / (unsigned)n_dev));
   std::vector<std::thread> workers;
   std::vector<std::exception_ptr> errors((size_t)n_dev);
   const size_t base = jobs.size() / n_dev, extra = jobs.size() % n_dev;
@@ -155,7 +181,7 @@ void HipCascadeHashMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs
     const size_t hi = lo + base + ((size_t)d < extra ? 1 : 0);
     workers.emplace_back([&, d, lo, hi] {
       try {
-        run_device(d % visible, sfm_data, flat, jobs, lo, hi, is_cross_valid);
+        run_device(d % visible, sfm_data, flat, jobs, lo, hi, is_cross_valid, helpers);
       } catch (...) {
         errors[(size_t)d] = std::current_exception();
       }
