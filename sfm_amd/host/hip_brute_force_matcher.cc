@@ -62,7 +62,7 @@ void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int
 // Two sets of pinned result buffers alternate, so the GPU works on batch b while this thread
 // turns batch b-1 into Match records.
 void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t hi, double ratio, bool cross,
-                int engine, Progress& progress) {
+                int engine, Progress& progress, int helpers) {
   sfm_hip_ctx* ctx = nullptr;
   if (sfm_hip_ctx_create(device, &ctx) != SFM_HIP_OK) fail(nullptr, "sfm_hip_ctx_create");
   struct Guard {
@@ -134,12 +134,35 @@ void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t 
                             stride) != SFM_HIP_OK)
       fail(ctx, "sfm_hip_match_pairs");
   };
+  // Building the records is the bulk of the host's work and every pair's list is independent: a
+  // few helper threads share a batch's pairs.
   auto collect = [&](size_t b0, const Set& s) {
     const size_t n = std::min(batch, n_jobs - b0);
-    for (size_t k = 0; k < n; k++) {
-      materialise(jobs[order[b0 + k]], s.lhs + k * stride, s.rhs + k * stride, s.counts[k]);
-      progress.pair_finished();
+    const size_t n_helpers = std::min<size_t>((size_t)helpers, n);
+    auto part = [&](size_t t) {
+      for (size_t k = t; k < n; k += n_helpers) {
+        materialise(jobs[order[b0 + k]], s.lhs + k * stride, s.rhs + k * stride, s.counts[k]);
+        progress.pair_finished();
+      }
+    };
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> failed(n_helpers);
+    for (size_t t = 1; t < n_helpers; t++)
+      pool.emplace_back([&, t] {
+        try {
+          part(t);
+        } catch (...) {
+          failed[t] = std::current_exception();
+        }
+      });
+    try {
+      part(0);
+    } catch (...) {
+      failed[0] = std::current_exception();
     }
+    for (auto& th : pool) th.join();
+    for (auto& f : failed)
+      if (f) std::rethrow_exception(f);
   };
 
   size_t which = 0;
@@ -204,6 +227,9 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
   const bool oversubscribe = over && std::string(over) == "1";
   const int n_dev = (int)std::min<size_t>((size_t)(oversubscribe ? want : std::min(want, visible)), jobs.size());
 
+  // host threads that turn index lists into Match records, per GPU
+  const unsigned cores = std::thread::hardware_concurrency();
+  const int helpers = (int)std::max(1u, std::min(8u, (cores ? cores : 8u) / (unsigned)n_dev));
   // static contiguous shards, sizes differ by at most one
   Progress progress;
   progress.total = (int)jobs.size();
@@ -216,7 +242,7 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
     const size_t hi = lo + base + ((size_t)d < extra ? 1 : 0);
     workers.emplace_back([&, d, lo, hi] {
       try {
-        run_device(d % visible, jobs, lo, hi, ratio_, is_cross_valid, engine, progress);
+        run_device(d % visible, jobs, lo, hi, ratio_, is_cross_valid, engine, progress, helpers);
       } catch (...) {
         errors[(size_t)d] = std::current_exception();
       }
