@@ -47,6 +47,17 @@ def test_null_arguments_are_rejected_not_dereferenced():
     assert lib.sfm_hip_device_count(None) != 0
     assert lib.sfm_hip_set_engine(None, 0) != 0
     assert b"null" in lib.sfm_hip_last_error(None)
+    # the cascade-hash and geometry entry points
+    assert lib.sfm_hip_cascade_set_projection(None, None, None) != 0
+    assert lib.sfm_hip_cascade_column_sums(None, None, 0, None) != 0
+    assert lib.sfm_hip_cascade_hash_images(None, None, 0, None) != 0
+    assert lib.sfm_hip_cascade_get_hashes(None, 0, None, None) != 0
+    assert lib.sfm_hip_cascade_match_pairs(None, None, 0, 1, None, None, None, None, None, 0) != 0
+    assert lib.sfm_hip_cascade_prepare(None, None, 0, None) != 0
+    assert lib.sfm_hip_cascade_get_stats(None, None) != 0
+    assert lib.sfm_hip_cascade_reference_projection(None, None) != 0
+    assert lib.sfm_hip_cascade_image_order(None, 1, None, None) != 0
+    assert lib.sfm_hip_geometry_verify_pairs(None, 0, None, None, None, 0, 0, None, None, None, None) != 0
 
 
 def test_product_code_never_touches_the_oracle():
