@@ -229,3 +229,15 @@ def test_large_and_unequal_images(matcher):
     matcher.cascade_prepare(pairs)
     assert _check_pairs(matcher, images, pairs, True) > 50
     assert _check_pairs(matcher, images, [(1, 0), (2, 0)], False) > 50    # first image the smaller one
+
+
+def test_image_size_limit_of_the_cascade_path(matcher):
+    """262,144 descriptors per image at most (the close-pair list lays out one count per 256 records
+    and group in LDS); one more is refused with a message, nothing is launched."""
+    big = np.zeros((262145, 128), np.float32)
+    _upload(matcher, {0: big, 1: big[:10]})
+    rp, rq = binding.cascade_reference_projection()
+    matcher.cascade_set_projection(rp, rq)
+    with pytest.raises(binding.SfmHipError, match="262,144"):
+        matcher.cascade_hash_images([0, 1], np.zeros(128, np.float32))
+    matcher.drop_all()

@@ -67,3 +67,14 @@ def test_inliers_are_the_planted_ones(matcher):
     assert (found & ~is_in).sum() < 0.05 * (~is_in).sum() + 3
     # rank two, and the planted matches lie on their epipolar lines
     assert abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-12
+
+
+def test_bad_arguments_are_refused(matcher):
+    from sfm_amd import binding
+    l, r, _ = synth.make_two_view_matches(20, 1.0, seed=1)
+    with pytest.raises(binding.SfmHipError, match="start at 0"):
+        matcher.geometry_verify_flat(np.array([1, 20], np.int64), l, r)
+    with pytest.raises(binding.SfmHipError, match="ascend"):
+        matcher.geometry_verify_flat(np.array([0, 20, 10], np.int64), l, r)
+    F, flags, counts, rounds = matcher.geometry_verify_flat(np.array([0], np.int64), l[:0], r[:0])
+    assert len(counts) == 0 and len(flags) == 0
