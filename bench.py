@@ -166,7 +166,10 @@ def roofline(st, engine, traffic):
     peak = PEAK_FP32_MFMA_TFLOPS if engine == "f32" else PEAK_FP16_MFMA_TFLOPS
     r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
          "traffic": traffic, "kernel": "k_distance_topk<%s>" % engine, "avg_launch_ms": avg_ms,
-         "flop_per_launch": per_launch}
+         "flop_per_launch": per_launch,
+         # the library brackets one launch in eight with HIP events (a start event is a packet of its
+         # own in front of the kernel and costs a few microseconds)
+         "timed_launches": st["distance_launches"]}
     if engine == "f16x3":
         # what the matrix units execute: 24 fp16 instructions of 32x32x16 and one fp32 32x32x2 per tile
         r["executed_over_algorithmic"] = (24 * 16 + 2) / 128.0
@@ -234,7 +237,7 @@ def main():
         torch.cuda.synchronize()
 
     def timed_region(engine):
-        """W untimed steps, then K timed steps between barriers; per-launch kernel timing on."""
+        """W untimed steps, then K timed steps between barriers; kernel timing on (one launch in eight)."""
         m.set_engine(engine)
         m.set_profiling(not args.no_profile_events)
         for _ in range(args.warmup):

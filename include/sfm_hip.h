@@ -45,7 +45,7 @@ typedef struct {
   uint64_t rescanned_queries; /* queries whose candidate set could not be proven complete and
                                  were answered by the exact full scan instead */
   uint64_t distance_launches; /* launches of the MFMA distance/top-k kernel that were timed */
-  double distance_ms;         /* their summed duration, from HIP events on the context's stream
+  double distance_ms;         /* their summed duration, from HIP events on the stream they ran on
                                  (only while profiling is enabled) */
   double distance_flop;       /* 2*Na*Nb*128 summed over those launches */
 } sfm_hip_stats;
@@ -55,7 +55,7 @@ int sfm_hip_device_count(int* count);
 
 /* Create / destroy a context bound to one device.  Replaces the reference's
  * per-call ThreadPool (src/internal/thread_pool.hpp:9-46,
- * brute_force_matcher.cc:44): the context owns a HIP stream and the device
+ * brute_force_matcher.cc:44): the context owns its HIP streams and the device
  * work space instead of two worker threads. */
 int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx);
 void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx);
@@ -104,8 +104,9 @@ int sfm_hip_image_size(sfm_hip_ctx* ctx, int64_t image_id, int32_t* n);
  * out_dist may be NULL.  All output buffers are host memory; pinned memory
  * (sfm_hip_host_alloc) keeps the copies asynchronous.
  *
- * The call returns once the work is queued on the context's stream; outputs
- * are valid after sfm_hip_sync().
+ * The call returns once the work is queued on the context's streams (it waits
+ * only when more than four batches are in flight); outputs are valid after
+ * sfm_hip_sync().
  */
 int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pairs, double ratio,
                         int cross_check, int32_t* out_counts, int32_t* out_lhs_idx,
@@ -133,13 +134,13 @@ int sfm_hip_sync(sfm_hip_ctx* ctx);
 void* sfm_hip_host_alloc(size_t bytes);
 void sfm_hip_host_free(void* p);
 
-/* Profiling: when enabled, every launch of the distance/top-k kernel is
- * bracketed by HIP events on the stream it runs on, and consecutive launches
- * are kept from overlapping (a context alternates between two streams so
- * that one batch's short tail kernels overlap the next batch's distance
- * kernel; with timing on, distance kernels additionally wait for each other,
- * which costs a few percent of throughput).  sfm_hip_get_stats() waits for
- * the queued work and folds the durations into distance_ms. */
+/* Profiling: when enabled, one launch in eight of the distance/top-k kernel (the first after
+ * sfm_hip_reset_stats or sfm_hip_get_stats among them) is bracketed by HIP events on the stream it
+ * runs on.  Distance kernels run one after the other on a stream of their own and each batch's short
+ * tail kernels on one of four other streams, so a launch never shares the chip with another launch
+ * of its kind; the start event is a packet of its own in front of the kernel and costs a few
+ * microseconds, which is why not every launch carries one.  sfm_hip_get_stats() waits for the
+ * queued work and folds the durations into distance_ms. */
 int sfm_hip_set_profiling(sfm_hip_ctx* ctx, int enabled);
 int sfm_hip_get_stats(sfm_hip_ctx* ctx, sfm_hip_stats* out);
 int sfm_hip_reset_stats(sfm_hip_ctx* ctx);

@@ -1010,21 +1010,28 @@ constexpr int RR_SQ_STRIDE = 132;    // words per row of squares (128 + 4: confl
 //      and checks the completeness bound;
 //   D. queries that failed the check are re-answered by an exact scan of every
 //      candidate row, by the whole workgroup.
-// PP = (query, candidate) pairs per pass of step B: 128 (two passes, 68 KiB of LDS: shortest
-// latency, for launches that do not fill the chip anyway) or 64 (four passes, 34 KiB and at most
-// 128 registers: twice the workgroups per compute unit, for batches, where the step is bound by
-// how many of its memory round trips are in flight).
+// PP = 64: step B in four passes of 64 (query, candidate) pairs through 34 KiB of LDS, with coalesced
+// row loads; for batches, where the step is bound by how many memory round trips are in flight (four
+// workgroups per compute unit).
+// PP = 0: the variant for launches that do not fill the chip (a single pair).  Step B without the
+// transposition through LDS: one lane per (query, candidate) reads both rows itself and adds up in
+// index order.  Its workgroups need 3.4 KiB of LDS and 104 registers, which is what a compute unit
+// has left beside a workgroup of k_distance_topk (152 KiB of LDS, one wave of 360 registers per
+// SIMD), so the re-rank of one pair can be resident while the next pair's distance kernel runs.
+// (It does not come for free then: beside the fp32 matrix instructions every vector instruction of
+// the re-rank still takes its turn on the SIMD; beside the fp16 ones it does overlap.)
 template <int PP>
-__global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev* __restrict__ pairs, double ratio,
-                                                                  int engine,
-                                                                  unsigned long long* __restrict__ rescanned) {
-  __shared__ __attribute__((aligned(16))) float sq[PP * RR_SQ_STRIDE];
+__global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ pairs, double ratio, int engine,
+                                                   unsigned long long* __restrict__ rescanned) {
+  static_assert(PP == 0 || PP == 64, "two variants");
+  __shared__ __attribute__((aligned(16))) float sq[PP > 0 ? PP * RR_SQ_STRIDE : DIM];
   __shared__ uint32_t cand[RR_QUERIES * NCAND];
   __shared__ uint32_t bnd[RR_QUERIES];
   __shared__ float res_r[RR_QUERIES * NCAND];
   __shared__ int unsafe_q[RR_QUERIES];
   __shared__ int mode[RR_QUERIES];
   __shared__ int n_unsafe;
+  __shared__ Top2 wave_part[4];
 
   const PairDev& P = pairs[blockIdx.y];
   const int dir = blockIdx.z;
@@ -1169,7 +1176,13 @@ __global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev*
 #endif
 
   // ---- B
-  {
+  if constexpr (PP == 0) {
+    const uint32_t ci = cand[tid];
+    float sum = __builtin_inff();
+    if (ci != SENT) sum = ref_sumsq(qbase + (size_t)(q0 + (tid >> 2)) * DIM, obase + (size_t)ci * DIM);
+    res_r[tid] = sum;
+    __syncthreads();
+  } else {
     const int w = tid >> 6, l = tid & 63, half = l >> 5, j = l & 31;
     // 256 / PP passes of PP (query, candidate) pairs.  A thread handles, for its 16 bytes of the
     // row, IT consecutive pairs = IT / 4 queries with their four candidates, so a query row is
@@ -1282,7 +1295,6 @@ __global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev*
   if (nu == 0) return;
   if (tid == 0) atomicAdd(rescanned, (unsigned long long)nu);
   float* qrow = sq;                                        // 128 floats
-  Top2* part = reinterpret_cast<Top2*>(sq + 128);          // 256 partial states
   for (int e = 0; e < nu; e++) {
     const int q = unsafe_q[e];
     __syncthreads();
@@ -1294,18 +1306,22 @@ __global__ __launch_bounds__(256, PP == 64 ? 4 : 2) void k_rerank(const PairDev*
       const float rsq = ref_sumsq(qrow, obase + (size_t)jj * DIM);
       top2_add(t, sqrtf(rsq), rsq, jj);
     }
-    part[tid] = t;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) {
-        Top2 a = part[tid];
-        top2_merge(a, part[tid + s]);
-        part[tid] = a;
-      }
-      __syncthreads();
+    // the 256 partial states: a butterfly inside each wavefront (the two sides of every exchange
+    // cover disjoint columns), then the four wavefronts' states through LDS
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      Top2 u;
+      u.d1 = __shfl_xor(t.d1, o); u.i1 = __shfl_xor(t.i1, o); u.d2 = __shfl_xor(t.d2, o);
+      u.r2 = __shfl_xor(t.r2, o); u.r1 = __shfl_xor(t.r1, o);
+      top2_merge(t, u);
     }
+    if ((tid & 63) == 0) wave_part[tid >> 6] = t;
+    __syncthreads();
     if (tid == 0) {
-      const Top2 r = part[0];
+      Top2 r = wave_part[0];
+      top2_merge(r, wave_part[1]);
+      top2_merge(r, wave_part[2]);
+      top2_merge(r, wave_part[3]);
       const bool accept = (double)r.d1 < ratio * (double)r.d2;
       int32_t* best = dir == 0 ? P.fwd_best : P.rev_best;
       float* dist = dir == 0 ? P.fwd_dist : P.rev_dist;

@@ -43,9 +43,15 @@ struct TimedLaunch {
   double flop;
 };
 
-// A lane = one stream with its own work space.  Consecutive batches alternate between the
-// lanes, so that the next batch's distance kernel starts while the previous batch's short
-// kernels (re-rank, compaction) are still draining; nothing is shared between two batches.
+// A lane = one stream with its own work space; nothing is shared between two batches.
+// Brute-force matcher: every batch's distance kernel goes to the context's distance stream, one
+// after the other with nothing in between, and its short tail (re-rank, compaction, copies) to the
+// stream of the batch's lane, which waits for that distance kernel through the event that rides on
+// its dispatch packet.  The tail of batch b then runs beside the distance kernel of batch b + 1
+// (its workgroups fit in what a distance workgroup leaves of a compute unit).  A lane is taken
+// again only after its previous tail has finished, which the host checks (a wait on the distance
+// stream would put a packet, and several microseconds, between two distance kernels).
+// Cascade-hash matcher: a batch's kernels all run on its lane's stream, lanes 0 and 1 in turn.
 struct Lane {
   hipStream_t stream = nullptr;
   // grow-only device work space
@@ -60,10 +66,13 @@ struct Lane {
   size_t stage_bytes[2] = {0, 0};
   hipEvent_t stage_free[2] = {nullptr, nullptr};
   int stage_slot = 0;
-  hipEvent_t last_distance_stop = nullptr;   // stop event of this lane's latest timed distance kernel
+  hipEvent_t distance_done = nullptr;   // rides on the lane's latest distance kernel
+  hipEvent_t tail_done = nullptr;       // recorded after the lane's latest tail
+  bool tail_pending = false;            // tail_done was recorded and not waited for yet
 };
 
-constexpr int N_LANES = 2;
+constexpr int N_LANES = 4;
+constexpr int N_CASCADE_LANES = 2;
 
 }  // namespace sfm_host
 
@@ -71,6 +80,9 @@ struct sfm_hip_ctx {
   int device = 0;
   sfm_host::Lane lanes[sfm_host::N_LANES];
   int next_lane = 0;
+  int next_cascade_lane = 0;
+  hipStream_t distance_stream = nullptr;   // all launches of the distance kernel, in order
+  unsigned launches_since_timed = 0;       // profiling: distance launches since the last timed one
   std::map<int64_t, sfm_host::Image> images;
   std::string last_error;
   unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
@@ -116,13 +128,18 @@ inline int fail(sfm_hip_ctx* ctx, int code, const std::string& msg) {
   } while (0)
 
 inline int sync_all(sfm_hip_ctx* ctx) {
-  for (Lane& l : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+  if (ctx->distance_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->distance_stream));
+  for (Lane& l : ctx->lanes) {
+    HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+    l.tail_pending = false;
+  }
   return SFM_HIP_OK;
 }
 
 inline int ensure(sfm_hip_ctx* ctx, Lane& L, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes) return SFM_HIP_OK;
-  // the old buffer may still be in use by work queued on its lane
+  // the old buffer may still be in use by work queued on its lane or on the distance stream
+  if (ctx->distance_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->distance_stream));
   HIP_TRY(ctx, hipStreamSynchronize(L.stream));
   if (b.p) HIP_TRY(ctx, hipFree(b.p));
   b.p = nullptr;

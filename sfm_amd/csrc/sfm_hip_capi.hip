@@ -46,6 +46,7 @@ void plan_chunks(PairPlan& pl, int row_blocks_in_batch_estimate, int target_bloc
 }
 
 constexpr int N_XCD = 8;
+constexpr unsigned PROFILE_EVERY = 8;   // profiling: one distance launch in this many is timed
 
 // Order of a pair's nrb x nch blocks (row block, chunk) for a launch whose first block of this pair
 // sits at a position congruent to first_pos modulo 8.  The grid is cut gr x gc = 8 ways, choosing the
@@ -103,7 +104,7 @@ int fold_timed(sfm_hip_ctx* ctx) {
     ctx->event_pool.push_back(t.stop);
   }
   ctx->timed.clear();
-  for (Lane& l : ctx->lanes) l.last_distance_stop = nullptr;   // its event went back to the pool
+  ctx->launches_since_timed = 0;   // the next launch is timed again
   return SFM_HIP_OK;
 }
 
@@ -144,7 +145,10 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
     if (e == hipSuccess && !ctx->upload_stream) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
     for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&l.stage_free[s], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&l.distance_done);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.tail_done, hipEventDisableTiming);
   }
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->distance_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->rescanned_dev, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(ctx->rescanned_dev, 0, sizeof(unsigned long long));
   if (e != hipSuccess) {
@@ -159,6 +163,7 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
 void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->distance_stream) (void)hipStreamSynchronize(ctx->distance_stream);
   for (Lane& l : ctx->lanes)
     if (l.stream) (void)hipStreamSynchronize(l.stream);
   for (auto& kv : ctx->images) free_image(kv.second);
@@ -169,8 +174,11 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
       if (l.stage_host[s]) (void)hipHostFree(l.stage_host[s]);
       if (l.stage_free[s]) (void)hipEventDestroy(l.stage_free[s]);
     }
+    if (l.distance_done) (void)hipEventDestroy(l.distance_done);
+    if (l.tail_done) (void)hipEventDestroy(l.tail_done);
     if (l.stream) (void)hipStreamDestroy(l.stream);
   }
+  if (ctx->distance_stream) (void)hipStreamDestroy(ctx->distance_stream);
   if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
   if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
   if (ctx->cascade_projection) (void)hipFree(ctx->cascade_projection);
@@ -323,6 +331,11 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
 
     Lane& L = ctx->lanes[ctx->next_lane];
     ctx->next_lane = (ctx->next_lane + 1) % N_LANES;
+    // the lane's work space is free once its previous tail has run
+    if (L.tail_pending) {
+      HIP_TRY(ctx, hipEventSynchronize(L.tail_done));
+      L.tail_pending = false;
+    }
 
     // ---- lay out the work space and build the tables
     size_t rowpart_words = 0, colpart_words = 0, best_words = 0, n_blocks = 0, n_queries = 0;
@@ -442,45 +455,47 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       }
     }
 
-    // ---- queue the batch
+    // ---- queue the batch: tables and distance kernel on the distance stream, the rest on the lane's
     hipStream_t st = L.stream;
+    hipStream_t ds = ctx->distance_stream;
     // The device keeps the previous batch's tables; identical tables (the same
     // pairs matched again) need no new upload.
     const bool same_tables = L.tables_shadow.size() == table_bytes &&
                              std::memcmp(L.tables_shadow.data(), L.stage_host[slot], table_bytes) == 0;
     if (!same_tables) {
-      HIP_TRY(ctx, hipMemcpyAsync(L.tables_dev.p, L.stage_host[slot], table_bytes, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipEventRecord(L.stage_free[slot], st));
+      HIP_TRY(ctx, hipMemcpyAsync(L.tables_dev.p, L.stage_host[slot], table_bytes, hipMemcpyHostToDevice, ds));
+      HIP_TRY(ctx, hipEventRecord(L.stage_free[slot], ds));
       L.tables_shadow.assign((char*)L.stage_host[slot], (char*)L.stage_host[slot] + table_bytes);
     }
 
     const PairDev* dp = (const PairDev*)L.tables_dev.p;
     const BlockDev* db = (const BlockDev*)((const char*)L.tables_dev.p + pairs_bytes);
     if (n_blocks) {
-      // While per-launch timing is on, a distance kernel waits for the other lane's previous
-      // one: a launch duration only means something when launches do not share the chip.
-      // (Without timing they are left free: the next launch's workgroups then take over compute
-      // units one by one as the previous launch's workgroups finish, which is worth a few percent.)
-      // With per-launch timing the start/stop events ride on the kernel's own dispatch packet
-      // (hipExtLaunchKernelGGL): separate event records would each put a marker packet, and
-      // several microseconds, between this kernel and its neighbours.
+      // The event the tail waits for rides on the kernel's own dispatch packet
+      // (hipExtLaunchKernelGGL): it costs nothing, where a separate event record puts a marker
+      // packet, and several microseconds, between this kernel and the next.  While profiling is
+      // on, one launch in PROFILE_EVERY also gets a start event -- such a marker packet -- and
+      // its duration goes into the statistics; the launches in between run as they always do.
       void (*kernel)(const PairDev*, const BlockDev*) =
           ctx->engine == SFM_HIP_ENGINE_F16X3 ? k_distance_topk<ENGINE_F16X3> : k_distance_topk<ENGINE_F32>;
-      if (ctx->profiling) {
-        for (Lane& o : ctx->lanes)
-          if (&o != &L && o.last_distance_stop) HIP_TRY(ctx, hipStreamWaitEvent(st, o.last_distance_stop, 0));
+      hipEvent_t done = L.distance_done;
+      if (ctx->profiling && ctx->launches_since_timed++ % PROFILE_EVERY == 0) {
         TimedLaunch tl{};
         tl.start = get_event(ctx);
         tl.stop = get_event(ctx);
         tl.flop = flop;
-        hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, tl.start, tl.stop, 0, dp, db);
+        hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, tl.start, tl.stop, 0, dp, db);
         HIP_TRY(ctx, hipGetLastError());
         ctx->timed.push_back(tl);
-        L.last_distance_stop = tl.stop;
+        done = tl.stop;
       } else {
-        hipLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, dp, db);
+        hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, nullptr, done, 0, dp, db);
         HIP_TRY(ctx, hipGetLastError());
       }
+      HIP_TRY(ctx, hipStreamWaitEvent(st, done, 0));
+    } else if (!same_tables) {
+      // no distance kernel to wait for, but the tail reads the tables
+      HIP_TRY(ctx, hipStreamWaitEvent(st, L.stage_free[slot], 0));
     }
     // Pairs with an empty image still go through the re-rank step: with no
     // candidates every query comes out unmatched, as in the reference.  Their
@@ -495,11 +510,12 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     if (max_q > 0) {
       const dim3 grid((max_q + RR_QUERIES - 1) / RR_QUERIES, count, cross_check ? 2 : 1);
       const int eng = ctx->engine == SFM_HIP_ENGINE_F16X3 ? ENGINE_F16X3 : ENGINE_F32;
-      // enough workgroups for several per compute unit: the variant that lets four of them share one
+      // enough workgroups for several per compute unit: the variant with coalesced row loads;
+      // otherwise the one that fits beside a distance workgroup
       if ((size_t)grid.x * grid.y * grid.z >= (size_t)4 * ctx->n_cu)
         hipLaunchKernelGGL(k_rerank<64>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev);
       else
-        hipLaunchKernelGGL(k_rerank<128>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev);
+        hipLaunchKernelGGL(k_rerank<0>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev);
       HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_cross_compact, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
@@ -514,6 +530,9 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
         if (out_dist) HIP_TRY(ctx, hipMemcpyAsync(out_dist + o, k_dist, out_words * 4, hipMemcpyDeviceToHost, st));
       }
     }
+
+    HIP_TRY(ctx, hipEventRecord(L.tail_done, st));
+    L.tail_pending = true;
 
     ctx->stats.pairs += (uint64_t)count;
     ctx->stats.queries += n_queries;

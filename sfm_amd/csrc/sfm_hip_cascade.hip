@@ -261,8 +261,8 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     const size_t segments = (size_t)GROUPS * n_walk;
     const size_t counters_at = align_up(slot_bytes, 256);
     const size_t zero_bytes = counters_at + align_up((size_t)count * 4, 256);
-    Lane& L = ctx->lanes[ctx->next_lane];
-    ctx->next_lane = (ctx->next_lane + 1) % N_LANES;
+    Lane& L = ctx->lanes[ctx->next_cascade_lane];
+    ctx->next_cascade_lane = (ctx->next_cascade_lane + 1) % N_CASCADE_LANES;
     hipStream_t st = L.stream;
     int rc;
     const size_t table_bytes = sizeof(CascadePair) * (size_t)count;

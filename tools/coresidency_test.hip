@@ -7,6 +7,7 @@
 //      distance kernel through an event), equal priorities
 //   D  as C, distance stream created with the highest priority, small-kernel stream the lowest
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -17,9 +18,14 @@ using namespace sfm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 // ~latency-bound stand-in: dependent global loads, 20 KiB of LDS, about 10 us per workgroup
-template <int LDS_INTS>
+// VREG > 0: the kernel claims that many vector registers (it touches the last one)
+template <int LDS_INTS, int VREG = 0>
 __global__ __launch_bounds__(256) void k_small(const int* __restrict__ chain, int* __restrict__ out, int hops) {
   __shared__ int pad[LDS_INTS];
+  if constexpr (VREG == 104) asm volatile("v_mov_b32 v103, 0" ::: "v103");
+  if constexpr (VREG == 64) asm volatile("v_mov_b32 v63, 0" ::: "v63");
+  if constexpr (VREG == 128) asm volatile("v_mov_b32 v127, 0" ::: "v127");
+  if constexpr (VREG == 144) asm volatile("v_mov_b32 v143, 0" ::: "v143");
   int i = (blockIdx.x * 256 + threadIdx.x) & 0xFFFF;
   for (int h = 0; h < hops; h++) i = chain[i];
   pad[threadIdx.x] = i;
@@ -106,5 +112,45 @@ int main(int argc, char** argv) {
     for (int i = 0; i < steps; i++) { k1(s_hi); CK(hipEventRecord(ev[i], s_hi)); CK(hipStreamWaitEvent(s_lo, ev[i], 0)); few(s_lo); } });
   timed("H small kernels free-running on their own stream (no events)", [&] {
     for (int i = 0; i < steps; i++) { k1(s_hi); small(s_lo); } });
+  // arrangements built on start/stop events that ride on the distance kernel's dispatch packet
+  std::vector<hipEvent_t> es(steps), ee(steps), et(steps);
+  for (int i = 0; i < steps; i++) { CK(hipEventCreate(&es[i])); CK(hipEventCreate(&ee[i])); CK(hipEventCreateWithFlags(&et[i], hipEventDisableTiming)); }
+  auto k1x = [&](hipStream_t st, hipEvent_t a, hipEvent_t b) {
+    hipExtLaunchKernelGGL(k_distance_topk<ENGINE_F32>, dim3(blocks.size()), dim3(256), 0, st, a, b, 0, dP, dB); };
+  hipStream_t lane[2] = {s_main, s_eq};
+  timed("I two lanes alternate; distance waits for the other lane's distance; tiny follows on the lane", [&] {
+    for (int i = 0; i < steps; i++) { hipStream_t st = lane[i & 1];
+      if (i > 0) CK(hipStreamWaitEvent(st, ee[i - 1], 0));
+      k1x(st, es[i], ee[i]); tiny(st); } });
+  timed("I' as I without the tiny kernel", [&] {
+    for (int i = 0; i < steps; i++) { hipStream_t st = lane[i & 1];
+      if (i > 0) CK(hipStreamWaitEvent(st, ee[i - 1], 0));
+      k1x(st, es[i], ee[i]); } });
+  timed("J distance kernels on one stream (stop event only); tiny on a second stream waits for it", [&] {
+    for (int i = 0; i < steps; i++) { k1x(s_main, nullptr, ee[i]); CK(hipStreamWaitEvent(s_eq, ee[i], 0)); tiny(s_eq); } });
+  timed("K as J with start and stop events", [&] {
+    for (int i = 0; i < steps; i++) { k1x(s_main, es[i], ee[i]); CK(hipStreamWaitEvent(s_eq, ee[i], 0)); tiny(s_eq); } });
+  timed("L as K; distance i also waits for tail i-2 (event recorded after the tiny kernel)", [&] {
+    for (int i = 0; i < steps; i++) {
+      if (i >= 2) CK(hipStreamWaitEvent(s_main, et[i - 2], 0));
+      k1x(s_main, es[i], ee[i]); CK(hipStreamWaitEvent(s_eq, ee[i], 0)); tiny(s_eq); CK(hipEventRecord(et[i], s_eq)); } });
+  auto run_j = [&](const char* name, auto launch_small) {
+    timed(name, [&] {
+      for (int i = 0; i < steps; i++) { k1x(s_main, nullptr, ee[i]); CK(hipStreamWaitEvent(s_eq, ee[i], 0)); launch_small(s_eq); } });
+  };
+  run_j("J2 as J, small kernel 3.5 KiB LDS, few registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<896, 0>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
+  run_j("J3 as J, small kernel 1 KiB LDS, 64 registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<256, 64>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
+  run_j("J4 as J, small kernel 1 KiB LDS, 104 registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<256, 104>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
+  run_j("J5 as J, small kernel 1 KiB LDS, 128 registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<256, 128>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
+  run_j("J6 as J, small kernel 1 KiB LDS, 144 registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<256, 144>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
+  run_j("J7 as J, small kernel 3.5 KiB LDS, 104 registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<896, 104>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
+  run_j("J8 as J, small kernel 6 KiB LDS, few registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<1536, 0>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
+  run_j("J9 as J, one workgroup of 1024 threads, 512 B LDS", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<128, 0>), dim3(1), dim3(256), 0, st, dchain, dout, hops); });
+  timed("M as K, start/stop events and nothing else", [&] {
+    for (int i = 0; i < steps; i++) { k1x(s_main, es[i], ee[i]); } });
+  timed("N as M, stop events only", [&] {
+    for (int i = 0; i < steps; i++) { k1x(s_main, nullptr, ee[i]); } });
+  { float ms = 0; double sum = 0; for (int i = 0; i < steps; i++) { CK(hipEventElapsedTime(&ms, es[i], ee[i])); sum += ms; }
+    printf("  (start->stop of the last arrangement with both: %.1f us per launch)\n", sum / steps * 1e3); }
   return 0;
 }
