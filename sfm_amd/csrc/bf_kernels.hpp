@@ -1032,7 +1032,12 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
   __shared__ int mode[RR_QUERIES];
   __shared__ int n_unsafe;
   __shared__ Top2 wave_part[4];
+  __shared__ uint16_t live[256];   // PP == 0: the (query, candidate) pairs that need a distance, densely
+  __shared__ int wave_live[4];
 
+#if defined(SFM_K2_STOP_AFTER) && SFM_K2_STOP_AFTER == 0
+  return;   // diagnostic build: the launch alone
+#endif
   const PairDev& P = pairs[blockIdx.y];
   const int dir = blockIdx.z;
   const int nq = dir == 0 ? P.na : P.nb;
@@ -1050,7 +1055,132 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
   const float other_max = (dir == 0 ? P.yn : P.xn)[dir == 0 ? P.nb_pad : P.na_pad];
 
   // ---- A
+  // First the three smallest keys of the query alone, values only (three v_med3/v_min per key): they
+  // decide nearly every query -- "the ratio test fails whatever the exact values are" or "the
+  // smallest key's column is the nearest and passes whatever they are" -- and such a query needs the
+  // column of its smallest key at most.  Only a wavefront that holds a query they do not decide goes
+  // through the full merge (five keys with their columns) below.
+  int md_fast = RR_FULL;
   {
+    const int ql = tid >> 2, sub = tid & 3;
+    const int q = q0 + ql;
+    const float nqv = q < nq ? qn_arr[q] : 0.0f;
+    uint32_t a0 = SENT, a1 = SENT, a2 = SENT, lbound = SENT, first = 0;   // first: column (dir 0) or row block (dir 1) of a0
+    if (q < nq) {
+      if (dir == 0) {
+        const size_t st = (size_t)P.na_pad;
+        for (int c0 = sub; c0 < P.nchunks; c0 += 8) {
+          uint32_t k[2][NCAND], ix[2][NCAND], b[2];
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int c = c0 + 4 * u;
+            const uint32_t* src = P.rowpart + (size_t)c * ROWPART_FIELDS * st + q;
+#pragma unroll
+            for (int e = 0; e < NCAND; e++) {
+              k[u][e] = c < P.nchunks ? src[e * st] : SENT;
+              ix[u][e] = c < P.nchunks ? src[(NCAND + e) * st] : 0u;
+            }
+            b[u] = c < P.nchunks ? src[2 * NCAND * st] : SENT;
+          }
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+#pragma unroll
+            for (int e = 0; e < NCAND; e++) {
+              first = k[u][e] < a0 ? ix[u][e] : first;
+              insert3(a0, a1, a2, k[u][e]);
+            }
+            lbound = lbound < b[u] ? lbound : b[u];
+          }
+        }
+      } else {
+        const size_t st = (size_t)P.nb_pad;
+        const int nrb = P.na_pad / BM;
+        for (int rb0 = sub; rb0 < nrb; rb0 += 32) {
+          uint32_t k[8][3];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int rb = rb0 + 4 * u;
+            const uint32_t* src = P.colpart + (size_t)rb * 3 * st + q;
+#pragma unroll
+            for (int e = 0; e < 3; e++) k[u][e] = rb < nrb ? src[e * st] : SENT;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            first = k[u][0] < a0 ? (uint32_t)(rb0 + 4 * u) : first;   // a list is ascending: its head decides
+#pragma unroll
+            for (int e = 0; e < 3; e++) insert3(a0, a1, a2, k[u][e]);
+            lbound = lbound < k[u][2] ? lbound : k[u][2];
+          }
+        }
+      }
+    }
+    // the four lanes of a query: two exchanges inside the quad (lanes l^1, then l^2)
+#define SFM_QUAD_XCHG(v, ctrl) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, false)
+#define SFM_QUAD_ROUND(ctrl)                                                                                   \
+    {                                                                                                          \
+      const uint32_t u0 = SFM_QUAD_XCHG(a0, ctrl), u1 = SFM_QUAD_XCHG(a1, ctrl), u2 = SFM_QUAD_XCHG(a2, ctrl); \
+      const uint32_t ub = SFM_QUAD_XCHG(lbound, ctrl), uf = SFM_QUAD_XCHG(first, ctrl);                        \
+      first = u0 < a0 ? uf : first;                                                                            \
+      insert3(a0, a1, a2, u0);                                                                                 \
+      insert3(a0, a1, a2, u1);                                                                                 \
+      insert3(a0, a1, a2, u2);                                                                                 \
+      lbound = lbound < ub ? lbound : ub;                                                                      \
+    }
+    SFM_QUAD_ROUND(0xB1)   // quad_perm [1, 0, 3, 2]
+    SFM_QUAD_ROUND(0x4E)   // quad_perm [2, 3, 0, 1]
+#undef SFM_QUAD_ROUND
+    // The four lanes hold the same keys now (equal keys may have left different columns in `first`:
+    // a query with equal smallest keys is never accepted from the keys alone).  One lane decides.
+    int md = RR_FULL;
+    if (sub == 0 && q < nq && no >= NCAND && lbound != SENT && a2 != SENT && (a2 & 0x7F800000u) != 0x7F800000u &&
+        ratio > 0.0 && ratio <= 1.0) {
+      // Every column's reference sum lies in [lower bound, upper bound] of its key; the columns
+      // outside the lists lie above the lower bound of the smallest list bound, and every column but
+      // the two smallest keys' above the lower bound of the third smallest key:
+      //   the nearest is >= min(lo_0, lx) and the second nearest <= hi_1:
+      //       sqrt(min(lo_0, lx)) >= ratio * sqrt(hi_1)  =>  brute_force_matcher.cc:35 fails;
+      //   column 0 <= hi_0 and everything else >= min(lo_1, lx):
+      //       sqrt(hi_0) < ratio * sqrt(min(lo_1, lx))   =>  column 0 is the nearest and passes.
+      // Square roots are taken of floats rounded outwards (sqrtf is monotone), in double as the rule.
+      const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
+      const uint32_t xkey = lbound < a2 ? lbound : a2;
+      double lo0, lo1, hi0, hi1, lx;
+      if (engine == ENGINE_F32) {
+        lo0 = excluded_lower_bound(a0, mask, nqv, other_max);
+        lo1 = excluded_lower_bound(a1, mask, nqv, other_max);
+        lx = excluded_lower_bound(xkey, mask, nqv, other_max);
+        hi0 = key_upper_bound(a0, mask, nqv, other_max);
+        hi1 = key_upper_bound(a1, mask, nqv, other_max);
+      } else {
+        const float sq = dir == 0 ? P.xscale[0] : P.yscale[0];
+        const float so = dir == 0 ? P.yscale[0] : P.xscale[0];
+        lo0 = excluded_lower_bound_split(a0, mask, nqv, other_max, sq, so);
+        lo1 = excluded_lower_bound_split(a1, mask, nqv, other_max, sq, so);
+        lx = excluded_lower_bound_split(xkey, mask, nqv, other_max, sq, so);
+        hi0 = key_upper_bound_split(a0, mask, nqv, other_max, sq, so);
+        hi1 = key_upper_bound_split(a1, mask, nqv, other_max, sq, so);
+      }
+      const double near_lo = fmax(0.0, fmin(lo0, lx)), rest_lo = fmax(0.0, fmin(lo1, lx));
+      if ((double)sqrtf(float_below(near_lo)) >= ratio * (double)sqrtf(float_above(hi1))) md = RR_REJECT;
+      else if ((double)sqrtf(float_above(hi0)) < ratio * (double)sqrtf(float_below(rest_lo))) md = RR_ACCEPT;
+      uint32_t c0 = SENT;
+      if (md == RR_ACCEPT) {
+        c0 = dir == 0 ? first : first * BM + col_key_row(a0 & COL_LOW);
+        if ((int)c0 >= no) md = RR_FULL;   // cannot happen for a finite key; the full merge sorts it out
+      }
+      if (md != RR_FULL) {
+        cand[tid + 0] = c0;
+        cand[tid + 1] = SENT;
+        cand[tid + 2] = SENT;
+        cand[tid + 3] = SENT;
+        bnd[ql] = xkey;
+        mode[ql] = md;
+      }
+    }
+    md_fast = __builtin_amdgcn_update_dpp(0, md, 0x00, 0xF, 0xF, false);   // quad_perm [0, 0, 0, 0]: the deciding lane's
+#undef SFM_QUAD_XCHG
+  }
+  if (__any(md_fast == RR_FULL)) {
     const int ql = tid >> 2, sub = tid & 3;
     const int q = q0 + ql;
     const float qn_early = q < nq ? qn_arr[q] : 0.0f;   // for the decision at the end of this step
@@ -1122,7 +1252,7 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
     bound = bound < t.v4 ? bound : t.v4;
     // The four lanes now hold the same five entries, but equal keys may sit in a different
     // order in each lane: one lane alone names the candidates.
-    if (sub == 0) {
+    if (sub == 0 && md_fast == RR_FULL) {
       uint32_t c0 = (t.v0 != SENT && (int)t.i0 < no) ? t.i0 : SENT;
       uint32_t c1 = (t.v1 != SENT && (int)t.i1 < no) ? t.i1 : SENT;
       uint32_t c2 = (t.v2 != SENT && (int)t.i2 < no) ? t.i2 : SENT;
@@ -1177,10 +1307,26 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
 
   // ---- B
   if constexpr (PP == 0) {
-    const uint32_t ci = cand[tid];
-    float sum = __builtin_inff();
-    if (ci != SENT) sum = ref_sumsq(qbase + (size_t)(q0 + (tid >> 2)) * DIM, obase + (size_t)ci * DIM);
-    res_r[tid] = sum;
+    // the pairs that need a distance (typically one per accepted query, a quarter of the slots at
+    // most) laid end to end, so that whole wavefronts have nothing to do
+    const bool lv = cand[tid] != SENT;
+    const unsigned long long bal = __ballot(lv);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) wave_live[wv] = __popcll(bal);
+    res_r[tid] = __builtin_inff();
+    __syncthreads();
+    int before = 0, n_live = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      before += k < wv ? wave_live[k] : 0;
+      n_live += wave_live[k];
+    }
+    if (lv) live[before + __popcll(bal & (((unsigned long long)1 << lane) - 1))] = (uint16_t)tid;
+    __syncthreads();
+    if (tid < n_live) {
+      const int p = live[tid];
+      res_r[p] = ref_sumsq(qbase + (size_t)(q0 + (p >> 2)) * DIM, obase + (size_t)cand[p] * DIM);
+    }
     __syncthreads();
   } else {
     const int w = tid >> 6, l = tid & 63, half = l >> 5, j = l & 31;
