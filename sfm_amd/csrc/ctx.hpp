@@ -69,6 +69,7 @@ struct Lane {
   hipEvent_t distance_done = nullptr;   // rides on the lane's latest distance kernel
   hipEvent_t tail_done = nullptr;       // recorded after the lane's latest tail
   bool tail_pending = false;            // tail_done was recorded and not waited for yet
+  bool half_queued = false;             // a distance kernel was queued and the call failed before its tail was
 };
 
 constexpr int N_LANES = 4;

@@ -312,7 +312,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     plans[p].Y = &iy->second;
   }
 
-  int done = 0;
+  int done = 0, rc0 = 0;
   while (done < n_pairs) {
     // ---- choose the batch: as many pairs as fit the work-space budget
     int remaining = n_pairs - done;
@@ -335,6 +335,10 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     if (L.tail_pending) {
       HIP_TRY(ctx, hipEventSynchronize(L.tail_done));
       L.tail_pending = false;
+    }
+    if (L.half_queued) {   // an earlier call failed between this lane's distance kernel and its tail
+      if ((rc0 = sync_all(ctx))) return rc0;
+      L.half_queued = false;
     }
 
     // ---- lay out the work space and build the tables
@@ -478,21 +482,27 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       // its duration goes into the statistics; the launches in between run as they always do.
       void (*kernel)(const PairDev*, const BlockDev*) =
           ctx->engine == SFM_HIP_ENGINE_F16X3 ? k_distance_topk<ENGINE_F16X3> : k_distance_topk<ENGINE_F32>;
-      hipEvent_t done = L.distance_done;
+      hipEvent_t finished = L.distance_done;
+      L.half_queued = true;
       if (ctx->profiling && ctx->launches_since_timed++ % PROFILE_EVERY == 0) {
         TimedLaunch tl{};
         tl.start = get_event(ctx);
         tl.stop = get_event(ctx);
         tl.flop = flop;
         hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, tl.start, tl.stop, 0, dp, db);
-        HIP_TRY(ctx, hipGetLastError());
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+          ctx->event_pool.push_back(tl.start);
+          ctx->event_pool.push_back(tl.stop);
+          HIP_TRY(ctx, e);
+        }
         ctx->timed.push_back(tl);
-        done = tl.stop;
+        finished = tl.stop;
       } else {
-        hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, nullptr, done, 0, dp, db);
+        hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, nullptr, finished, 0, dp, db);
         HIP_TRY(ctx, hipGetLastError());
       }
-      HIP_TRY(ctx, hipStreamWaitEvent(st, done, 0));
+      HIP_TRY(ctx, hipStreamWaitEvent(st, finished, 0));
     } else if (!same_tables) {
       // no distance kernel to wait for, but the tail reads the tables
       HIP_TRY(ctx, hipStreamWaitEvent(st, L.stage_free[slot], 0));
@@ -533,6 +543,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
 
     HIP_TRY(ctx, hipEventRecord(L.tail_done, st));
     L.tail_pending = true;
+    L.half_queued = false;
 
     ctx->stats.pairs += (uint64_t)count;
     ctx->stats.queries += n_queries;

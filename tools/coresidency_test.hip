@@ -99,6 +99,7 @@ int main(int argc, char** argv) {
   // the small kernel alone
   timed("small kernel alone, back to back", [&] { for (int i = 0; i < steps; i++) small(s_main); });
   timed("A distance kernel only", [&] { for (int i = 0; i < steps; i++) k1(s_main); });
+  timed("A2 distance kernels on two streams in turn, nothing else", [&] { for (int i = 0; i < steps; i++) k1(i & 1 ? s_eq : s_main); });
   timed("B distance + small alternating on one stream", [&] { for (int i = 0; i < steps; i++) { k1(s_main); small(s_main); } });
   timed("C two streams, equal priority", [&] {
     for (int i = 0; i < steps; i++) { k1(s_main); CK(hipEventRecord(ev[i], s_main)); CK(hipStreamWaitEvent(s_eq, ev[i], 0)); small(s_eq); } });
