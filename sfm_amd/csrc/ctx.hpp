@@ -69,6 +69,10 @@ struct Lane {
   hipEvent_t distance_done = nullptr;   // rides on the lane's latest distance kernel
   hipEvent_t tail_done = nullptr;       // recorded after the lane's latest tail
   bool tail_pending = false;            // tail_done was recorded and not waited for yet
+  // host memory the lane's latest tail writes (counts, lhs, rhs, distances): a later batch on another
+  // lane that writes any of it again waits for this tail, so that results land in call order
+  const char* out_lo[4] = {nullptr, nullptr, nullptr, nullptr};
+  const char* out_hi[4] = {nullptr, nullptr, nullptr, nullptr};
   bool half_queued = false;             // a distance kernel was queued and the call failed before its tail was
 };
 

@@ -250,3 +250,93 @@ def test_ratio_test_at_its_threshold(matcher, scale):
     l, r, d = check_pair(matcher, A, B, False)
     assert 0.2 * n < len(l) < 0.8 * n                          # the cases really fall on both sides
     check_pair(matcher, A, B, True)
+
+
+def _queue_call(m, lib, pair, stride, bufs):
+    import ctypes
+    p = np.array([pair], np.int64)
+    cnt, lhs, rhs, dist = bufs
+    rc = lib.sfm_hip_match_pairs(m._h, p.ctypes.data, 1, ctypes.c_double(0.8), 1, cnt.ptr, lhs.ptr, rhs.ptr, dist.ptr, stride)
+    assert rc == 0, lib.sfm_hip_last_error(m._h)
+
+
+def test_many_calls_in_flight_each_with_buffers_of_its_own(matcher):
+    """Twelve single-pair calls queued without a sync in between (more than the context has lanes),
+    every call with output buffers of its own: every call's result must be the oracle's."""
+    import sfm_amd
+    from sfm_amd.binding import _Pinned
+    lib = sfm_amd.library()
+    sizes = [700, 333, 1024, 512, 90]
+    imgs = [im[:n] for im, n in zip(synth.make_image_set(5, 1024, 0.5, seed=77), sizes)]
+    for i, im in enumerate(imgs):
+        matcher.upload(300 + i, im)
+    pairs = [(300 + a, 300 + b) for a in range(5) for b in range(5) if a != b][:12]
+    stride = 1024
+    sets = [[_Pinned(lib, s, t) for s, t in (((1,), np.int32), ((1, stride), np.int32), ((1, stride), np.int32),
+                                             ((1, stride), np.float32))] for _ in pairs]
+    try:
+        for pair, bufs in zip(pairs, sets):
+            _queue_call(matcher, lib, pair, stride, bufs)
+        matcher.sync()
+        for (a, b), (cnt, lhs, rhs, dist) in zip(pairs, sets):
+            c = int(cnt.array[0])
+            got = (lhs.array[0, :c].astype(np.int64), rhs.array[0, :c].astype(np.int64), dist.array[0, :c].copy())
+            assert_same(got, oracle.match_pair(imgs[a - 300], imgs[b - 300], 0.8, True), "pair %s" % ((a, b),))
+    finally:
+        matcher.sync()
+        for bufs in sets:
+            for b in bufs:
+                b.free()
+
+
+def test_calls_in_flight_that_reuse_output_buffers_land_in_call_order(matcher):
+    """Two sets of output buffers used in turn by ten calls in flight.  The last but one call on
+    either set has a slow tail (identical descriptors: every query is answered by the exact full
+    scan) and the small pair after it is done long before that tail is: each set must still end up
+    holding its LAST call's result."""
+    import sfm_amd
+    from sfm_amd.binding import _Pinned
+    lib = sfm_amd.library()
+    big = [np.tile(synth.rootsift_rows(1, 3), (n, 1)) for n in (3000, 2900)]
+    small = [im[:n] for im, n in zip(synth.make_image_set(4, 256, 0.5, seed=92), [200, 256, 64, 130])]
+    for i, im in enumerate(big):
+        matcher.upload(400 + i, im)
+    for i, im in enumerate(small):
+        matcher.upload(410 + i, im)
+    where = {400: big[0], 401: big[1], 410: small[0], 411: small[1], 412: small[2], 413: small[3]}
+    calls = [(410, 411), (412, 413), (411, 410), (413, 412), (410, 413), (413, 410), (400, 401), (401, 400),
+             (411, 412), (412, 410)]
+    stride = 4096
+    sets = [[_Pinned(lib, s, t) for s, t in (((1,), np.int32), ((1, stride), np.int32), ((1, stride), np.int32),
+                                             ((1, stride), np.float32))] for _ in range(2)]
+    try:
+        for k, pair in enumerate(calls):
+            _queue_call(matcher, lib, pair, stride, sets[k & 1])
+        matcher.sync()
+        for which in (0, 1):
+            a, b = [p for k, p in enumerate(calls) if (k & 1) == which][-1]
+            cnt, lhs, rhs, dist = sets[which]
+            c = int(cnt.array[0])
+            got = (lhs.array[0, :c].astype(np.int64), rhs.array[0, :c].astype(np.int64), dist.array[0, :c].copy())
+            assert_same(got, oracle.match_pair(where[a], where[b], 0.8, True), "set %d" % which)
+    finally:
+        matcher.sync()
+        for bufs in sets:
+            for b in bufs:
+                b.free()
+
+
+def test_profiling_times_one_launch_in_eight(matcher):
+    A, B, _ = synth.make_pair(512, 512, 100, seed=3)
+    matcher.upload(0, A)
+    matcher.upload(1, B)
+    matcher.set_profiling(True)
+    matcher.reset_stats()
+    for _ in range(17):
+        matcher.match_pairs_async([(0, 1)], 0.8, True)
+    st = matcher.stats()
+    matcher.set_profiling(False)
+    assert st["pairs"] == 17
+    assert st["distance_launches"] == 3            # launches 0, 8 and 16
+    assert st["distance_ms"] > 0.0
+    assert st["distance_flop"] == 3 * 2.0 * 512 * 512 * 128
