@@ -106,7 +106,9 @@ int sfm_hip_image_size(sfm_hip_ctx* ctx, int64_t image_id, int32_t* n);
  *
  * The call returns once the work is queued on the context's streams (it waits
  * only when more than four batches are in flight); outputs are valid after
- * sfm_hip_sync().
+ * sfm_hip_sync().  A later call may be handed output memory that an earlier,
+ * still unfinished call writes: the results land in call order, so the memory
+ * ends up holding the later call's.
  */
 int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pairs, double ratio,
                         int cross_check, int32_t* out_counts, int32_t* out_lhs_idx,
