@@ -62,7 +62,7 @@ def cascade_cpu_baseline(images, pairs, got):
             "matches_equal_gpu": bool(same)}
 
 
-def cascade_leg(m, with_cpu, n_images=32, reps=10):
+def cascade_leg(m, with_cpu, n_images=32, reps=40):
     """The cascade-hash matcher (the one the reference's driver runs) on the same GPU: all pairs of
     a synthetic set with repeated structure, descriptors and hashes resident.  value counts
     back-to-back batches; the roofline figure comes from batches run one at a time between HIP
@@ -78,7 +78,7 @@ def cascade_leg(m, with_cpu, n_images=32, reps=10):
     t0 = time.perf_counter()
     m.cascade_prepare(pairs)
     prepare_s = time.perf_counter() - t0
-    for _ in range(2):
+    for _ in range(20):   # ~12 ms: the first batches after a change of workload run slower
         out = m.cascade_match_pairs_async(pairs, True, stride=N_FEATURES)
     m.sync()
     n_matches, n_defaults = int(out[1].sum()), int(out[0].sum())

@@ -559,17 +559,25 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ch_walk_nearest(const CascadeP
 }
 
 // ---------------------------------------------------------------------------------------------
-// One thread per close pair of a pair's list: the state of both descriptors from their histograms
-// (every thread that names a descriptor stores the same value), then, if the pair lies inside the
-// bins taken for either of them, its distance.  grid: (blocks, 1, pairs); the workgroup lays the
-// segments' counts end to end and its threads stride the entries.
+// The close pairs of a pair's list, 64 at a time: the state of both descriptors from their
+// histograms (every thread that names a descriptor stores the same value), then, for the close pairs
+// that lie inside the bins taken for either of them, the exact distance.  grid: (blocks, 1, pairs);
+// the workgroup lays the segments' counts end to end and its tiles of 64 entries stride the list.
+// The two 512-byte rows of a close pair are read by 32 lanes with 16 bytes each (whole cache lines;
+// one lane reading a row alone touches a line of its own with every load), the squared differences
+// go through LDS, and one lane per close pair adds them up in index order: src/metric.hpp:15-22.
+// Dynamic LDS: (segments + 1) words.
 // ---------------------------------------------------------------------------------------------
 constexpr int NEAREST_MAX_SEGMENTS = GROUPS * (MAX_IMAGE_ROWS / 256);
+constexpr int NEAREST_TILE = 64;
+constexpr int NEAREST_SQ_STRIDE = 132;   // words per row of squares (128 + 4: conflict-free 16-byte reads)
 
-__global__ __launch_bounds__(256) void k_ch_nearest(const CascadePair* __restrict__ pairs, int both_directions,
-                                                    int segments) {
-  __shared__ uint32_t start[NEAREST_MAX_SEGMENTS + 1];   // start[s] = entries in the segments before s
+__global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __restrict__ pairs, int both_directions,
+                                                       int segments) {
+  extern __shared__ uint32_t start[];   // start[s] = entries in the segments before s
   __shared__ uint32_t wave_sum[4];
+  __shared__ __attribute__((aligned(16))) float sq[NEAREST_TILE * NEAREST_SQ_STRIDE];
+  __shared__ uint32_t ent_i[NEAREST_TILE], ent_j[NEAREST_TILE], ent_f[NEAREST_TILE];   // ent_f: 1 = into a, 2 = into b
   const CascadePair& P = pairs[blockIdx.z];
   if (*P.overflow != 0) return;   // incomplete list: k_ch_take_all + k_ch_walk_nearest do this pair
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -600,26 +608,79 @@ __global__ __launch_bounds__(256) void k_ch_nearest(const CascadePair* __restric
   if (tid == 255) start[segments] = before;   // the last thread ends up with the total
   __syncthreads();
   const uint32_t total = start[segments];
-  for (uint32_t k = blockIdx.x * 256 + tid; k < total; k += gridDim.x * 256) {
-    // the segment that holds entry k: the last one that starts at or before k
-    int lo = 0, hi = segments - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (start[mid] <= k) lo = mid;
-      else hi = mid - 1;
+  for (uint32_t t0 = blockIdx.x * NEAREST_TILE; t0 < total; t0 += gridDim.x * NEAREST_TILE) {
+    // one lane per entry: the bins decisions
+    if (tid < NEAREST_TILE) {
+      uint32_t i = 0, j = 0, f = 0;
+      const uint32_t k = t0 + (uint32_t)tid;
+      if (k < total) {
+        // the segment that holds entry k: the last one that starts at or before k
+        int lo = 0, hi = segments - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (start[mid] <= k) lo = mid;
+          else hi = mid - 1;
+        }
+        const uint2 entry = P.list[(size_t)lo * LIST_SEGMENT + (k - start[lo])];
+        i = entry.x;
+        j = entry.y & ((1u << LIST_H_SHIFT) - 1u);
+        const uint32_t h = entry.y >> LIST_H_SHIFT;
+        const uint32_t state_a = take_state(P.hist_a + (size_t)i * HIST_WORDS);
+        P.res_a[(size_t)i * RES_WORDS + RES_STATE] = state_a;
+        if (inside_taken_bins(state_a, h)) f |= 1u;
+        if (both_directions) {
+          const uint32_t state_b = take_state(P.hist_b + (size_t)j * HIST_WORDS);
+          P.res_b[(size_t)j * RES_WORDS + RES_STATE] = state_b;
+          if (inside_taken_bins(state_b, h)) f |= 2u;
+        }
+        if (f == 0) i = j = 0;   // no distance needed: the loads below go to row 0 and are not used
+      }
+      ent_i[tid] = i;
+      ent_j[tid] = j;
+      ent_f[tid] = f;
     }
-    const uint2 entry = P.list[(size_t)lo * LIST_SEGMENT + (k - start[lo])];
-    const uint32_t i = entry.x, j = entry.y & ((1u << LIST_H_SHIFT) - 1u), h = entry.y >> LIST_H_SHIFT;
-    const uint32_t state_a = take_state(P.hist_a + (size_t)i * HIST_WORDS);
-    P.res_a[(size_t)i * RES_WORDS + RES_STATE] = state_a;
-    bool fb = false;
-    if (both_directions) {
-      const uint32_t state_b = take_state(P.hist_b + (size_t)j * HIST_WORDS);
-      P.res_b[(size_t)j * RES_WORDS + RES_STATE] = state_b;
-      fb = inside_taken_bins(state_b, h);
+    __syncthreads();
+    // 32 lanes per row: eight entries per half-wavefront, all sixteen loads on their way before the
+    // first is used (no branches: an entry that needs no distance reads row 0)
+    {
+#pragma clang fp contract(off)
+      const int half = lane >> 5, jj = lane & 31;
+      float4 a[8], b[8];
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int e = wv * 16 + half * 8 + it;
+        a[it] = reinterpret_cast<const float4*>(P.da + (size_t)ent_i[e] * DIM)[jj];
+        b[it] = reinterpret_cast<const float4*>(P.db + (size_t)ent_j[e] * DIM)[jj];
+      }
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int e = wv * 16 + half * 8 + it;
+        float4 d;
+        d.x = a[it].x - b[it].x; d.y = a[it].y - b[it].y; d.z = a[it].z - b[it].z; d.w = a[it].w - b[it].w;
+        d.x = d.x * d.x; d.y = d.y * d.y; d.z = d.z * d.z; d.w = d.w * d.w;
+        *reinterpret_cast<float4*>(sq + e * NEAREST_SQ_STRIDE + 4 * jj) = d;
+      }
     }
-    const bool fa = inside_taken_bins(state_a, h);
-    if (fa || fb) fold_distance(P, i, j, fa, fb);
+    __syncthreads();
+    if (tid < NEAREST_TILE && ent_f[tid] != 0) {
+#pragma clang fp contract(off)
+      const float4* s4 = reinterpret_cast<const float4*>(sq + tid * NEAREST_SQ_STRIDE);
+      float sum = 0.0f;
+#pragma unroll 8
+      for (int k = 0; k < DIM / 4; k++) {
+        const float4 v = s4[k];
+        sum = sum + v.x;
+        sum = sum + v.y;
+        sum = sum + v.z;
+        sum = sum + v.w;
+      }
+      // (a - b)^2 and (b - a)^2 are the same float: one distance serves both directions
+      const uint32_t i = ent_i[tid], j = ent_j[tid], f = ent_f[tid];
+      const unsigned long long hi = (unsigned long long)__float_as_uint(sqrtf(sum)) << 32;
+      if (f & 1u) atomicMax(reinterpret_cast<unsigned long long*>(P.res_a + (size_t)i * RES_WORDS + RES_BEST), ~(hi | j));
+      if (f & 2u) atomicMax(reinterpret_cast<unsigned long long*>(P.res_b + (size_t)j * RES_WORDS + RES_BEST), ~(hi | i));
+    }
+    __syncthreads();   // the tile's arrays are free again
   }
 }
 
@@ -644,7 +705,7 @@ __global__ __launch_bounds__(256) void k_ch_take_all(const CascadePair* __restri
 }
 
 // Cross-check (cascade_hash_matcher.cc:182-193) and ordered compaction.  One workgroup of 1024
-// threads per pair, eight consecutive queries per thread and sweep: output order is ascending
+// threads per pair, sweeps of 1024 consecutive queries, one per thread: output order is ascending
 // lhs index.  out_defaults: the records `Matches temp(matches.size())` holds before the survivors
 // are appended (.cc:187) -- one per forward match, cross-check only.  Every slot that was touched
 // goes back to zero, and so does the list's overflow mark.
@@ -655,92 +716,66 @@ __device__ __forceinline__ void clear_query(uint32_t* hist_row, uint32_t* res) {
   *reinterpret_cast<uint4*>(res) = z;
 }
 
-__global__ __launch_bounds__(1024) void k_ch_compact(const CascadePair* __restrict__ pairs, int cross_check,
+constexpr int CH_COMPACT_THREADS = 1024;
+__global__ __launch_bounds__(CH_COMPACT_THREADS) void k_ch_compact(const CascadePair* __restrict__ pairs, int cross_check,
                                                      int32_t* __restrict__ out_defaults,
                                                      int32_t* __restrict__ out_counts, int32_t* __restrict__ out_lhs,
                                                      int32_t* __restrict__ out_rhs, float* __restrict__ out_dist,
                                                      int64_t out_stride) {
-  __shared__ int wkeep[16], wfwd[16];
-  __shared__ int base_keep, base_fwd;
+  __shared__ int wkeep[2][CH_COMPACT_THREADS / 64], wfwd[2][CH_COMPACT_THREADS / 64];   // per wavefront and sweep parity: one barrier per sweep
   const CascadePair& P = pairs[blockIdx.x];
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  const unsigned long long below = ((unsigned long long)1 << l) - 1;
   const size_t ob = (size_t)P.out_slot * (size_t)out_stride;
-  if (tid == 0) {
-    base_keep = 0;
-    base_fwd = 0;
-  }
-  __syncthreads();
-  for (int i0 = 0; i0 < P.na; i0 += 8192) {
-    const int ib = i0 + tid * 8;
-    int j[8];
-    float d[8];
-    bool keep[8];
-    int nfwd = 0, cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int i = ib + k;
-      keep[k] = false;
-      j[k] = 0;
-      d[k] = 0.0f;
-      if (i < P.na) {
-        uint32_t* ra = P.res_a + (size_t)i * RES_WORDS;
-        const uint4 t = *reinterpret_cast<const uint4*>(ra);     // state, -, best (inverted) low, high
-        if (t.x != 0) clear_query(P.hist_a + (size_t)i * HIST_WORDS, ra);   // only this thread ever reads query i
-        if (t.x >= STATE_MATCH) {
-          nfwd++;
-          j[k] = (int)~t.z;
-          d[k] = __uint_as_float(~t.w);
-          keep[k] = true;
-          if (cross_check) {
-            const uint4 u = *reinterpret_cast<const uint4*>(P.res_b + (size_t)j[k] * RES_WORDS);
-            keep[k] = u.x >= STATE_MATCH && (int)~u.z == i;
-          }
+  int base_keep = 0, base_fwd = 0;   // the same in every thread
+  // One query per thread and sweep, 1,024 consecutive queries per sweep: a wavefront reads 1 KiB of
+  // consecutive result words per instruction (eight consecutive queries per thread would have every
+  // lane on a cache line of its own, eight times over).
+  for (int i0 = 0, sweep = 0; i0 < P.na; i0 += CH_COMPACT_THREADS, sweep ^= 1) {
+    const int i = i0 + tid;
+    int j = 0;
+    float d = 0.0f;
+    bool keep = false, fwd = false;
+    if (i < P.na) {
+      uint32_t* ra = P.res_a + (size_t)i * RES_WORDS;
+      const uint4 t = *reinterpret_cast<const uint4*>(ra);     // state, -, best (inverted) low, high
+      if (t.x != 0) clear_query(P.hist_a + (size_t)i * HIST_WORDS, ra);   // only this thread ever reads query i
+      if (t.x >= STATE_MATCH) {
+        fwd = true;
+        j = (int)~t.z;
+        d = __uint_as_float(~t.w);
+        keep = true;
+        if (cross_check) {
+          const uint4 u = *reinterpret_cast<const uint4*>(P.res_b + (size_t)j * RES_WORDS);
+          keep = u.x >= STATE_MATCH && (int)~u.z == i;
         }
       }
-      cnt += keep[k] ? 1 : 0;
     }
-    int incl = cnt, incl_f = nfwd;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o);
-      const int vf = __shfl_up(incl_f, o);
-      if (l >= o) {
-        incl += v;
-        incl_f += vf;
-      }
-    }
-    if (l == 63) {
-      wkeep[wv] = incl;
-      wfwd[wv] = incl_f;
+    const unsigned long long mk = __ballot(keep), mf = __ballot(fwd);
+    if (l == 0) {
+      wkeep[sweep][wv] = __popcll(mk);
+      wfwd[sweep][wv] = __popcll(mf);
     }
     __syncthreads();
     int before = base_keep;
-    for (int k = 0; k < wv; k++) before += wkeep[k];
-    int pos = before + incl - cnt;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (keep[k]) {
-        const size_t o = ob + (size_t)pos++;
-        out_lhs[o] = ib + k;
-        out_rhs[o] = j[k];
-        out_dist[o] = d[k];
-      }
+    for (int k = 0; k < CH_COMPACT_THREADS / 64; k++) {
+      const int c = wkeep[sweep][k];
+      before += k < wv ? c : 0;
+      base_keep += c;
+      base_fwd += wfwd[sweep][k];
     }
-    __syncthreads();
-    if (tid == 0) {
-      int s = base_keep, f = base_fwd;
-      for (int k = 0; k < 16; k++) {
-        s += wkeep[k];
-        f += wfwd[k];
-      }
-      base_keep = s;
-      base_fwd = f;
+    if (keep) {
+      const size_t o = ob + (size_t)(before + __popcll(mk & below));
+      out_lhs[o] = i;
+      out_rhs[o] = j;
+      out_dist[o] = d;
     }
-    __syncthreads();
   }
+  __syncthreads();
   // the second image's slots were read by any thread above: cleared only now
   if (cross_check) {
-    for (int q = tid; q < P.nb; q += 1024) {
+    for (int q = tid; q < P.nb; q += CH_COMPACT_THREADS) {
       uint32_t* rb = P.res_b + (size_t)q * RES_WORDS;
       if (rb[RES_STATE] != 0) clear_query(P.hist_b + (size_t)q * HIST_WORDS, rb);
     }

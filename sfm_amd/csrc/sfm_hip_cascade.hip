@@ -363,7 +363,8 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       hipLaunchKernelGGL(k_ch_walk_count, dim3((unsigned)n_walk, GROUPS, (unsigned)count), dim3(WALK_THREADS), 0, st, dp,
                          both);
       HIP_TRY(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_ch_nearest, dim3(NEAREST_BLOCKS, 1, (unsigned)count), dim3(256), 0, st, dp, both, (int)segments);
+      hipLaunchKernelGGL(k_ch_nearest, dim3(NEAREST_BLOCKS, 1, (unsigned)count), dim3(256), (segments + 1) * sizeof(uint32_t),
+                         st, dp, both, (int)segments);
       HIP_TRY(ctx, hipGetLastError());
       // the two kernels below return at once for every pair whose list was complete
       hipLaunchKernelGGL(k_ch_take_all, dim3(FALLBACK_BLOCKS, cross_check ? 2 : 1, (unsigned)count), dim3(256), 0, st, dp,
@@ -373,7 +374,7 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
                          both);
       HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_ch_compact, dim3((unsigned)count), dim3(1024), 0, st, dp, both, k_defaults, k_counts, k_lhs, k_rhs,
+    hipLaunchKernelGGL(k_ch_compact, dim3((unsigned)count), dim3(CH_COMPACT_THREADS), 0, st, dp, both, k_defaults, k_counts, k_lhs, k_rhs,
                        k_dist, out_stride);
     HIP_TRY(ctx, hipGetLastError());
     L.cascade_slots_dirty = false;

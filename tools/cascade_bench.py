@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=32)
     ap.add_argument("--features", type=int, default=8192)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--no-cross-check", action="store_true")
     a = ap.parse_args()
