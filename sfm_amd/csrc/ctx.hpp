@@ -105,6 +105,8 @@ struct sfm_hip_ctx {
 
   // geometric verification: grow-only device buffers kept between calls
   sfm_host::DevBuf geometry_buffers[11];
+  hipStream_t geometry_readback = nullptr;   // reads a launch's "unfinished" counter while the next launch runs
+  hipEvent_t geometry_events[16] = {};       // one per launch of a call
 
   // cascade-hash matcher
   float* cascade_projection = nullptr;   // device: [128 + 60][128] projection rows, then the 128-float mean

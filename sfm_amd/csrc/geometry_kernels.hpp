@@ -294,42 +294,97 @@ __global__ __launch_bounds__(ROUNDS_PER_LAUNCH) void k_geo_count(const GeoPair* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// ransac.hpp:126-142 over the launch's results in round order.  One thread per pair.
+// ransac.hpp:126-142 over the launch's results in round order.  One wavefront per pair, four
+// consecutive slots per lane.  The sequential loop
+//     while (N > rounds) { rounds++; if (count == n) { take it; stop; }
+//                          N = min(N, needed[count]); if (count > best) take it; }
+// is a prefix minimum (N on entry to a slot), the first slot at which it stops -- before the slot
+// when N <= rounds, after it when everything is an inlier -- and, over the slots before that point,
+// the largest count at its first occurrence.  Slots the fit skipped (at or beyond N at the launch's
+// start) hold stale counts; they lie behind the stopping point and never reach the result.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t u = __shfl_xor(v, o);
+    v = u < v ? u : v;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restrict__ pairs, int n_pairs,
                                                         uint32_t* __restrict__ unfinished) {
-  const int p = blockIdx.x * 64 + threadIdx.x;
+  static_assert(ROUNDS_PER_LAUNCH == 256, "four slots per lane");
+  const int p = blockIdx.x;
   if (p >= n_pairs) return;
   const GeoPair P = pairs[p];
   GeoState* st = P.state;
   if (st->done) return;
-  uint32_t limit = st->rounds_limit, done_rounds = st->rounds_done, best = st->best_count;
-  bool finished = false;
-  for (uint32_t slot = 0; slot < (uint32_t)ROUNDS_PER_LAUNCH && !finished; slot++) {
-    if (!(limit > done_rounds)) {      // while (N > sample_count)
-      finished = true;
-      break;
+  const uint32_t limit0 = st->rounds_limit, done0 = st->rounds_done, best0 = st->best_count;
+  const int l = threadIdx.x;
+  const uint32_t NONE = 0xFFFFFFFFu;
+  uint32_t cnt[4], need[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) cnt[k] = P.hyp_count[4 * l + k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) need[k] = cnt[k] <= (uint32_t)P.n ? P.rounds_needed[cnt[k]] : NONE;
+  // N on entry to every slot: limit0 and the needs of all earlier slots
+  uint32_t lane_min = min(min(need[0], need[1]), min(need[2], need[3]));
+  uint32_t incl = lane_min;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o);
+    if (l >= o) incl = min(incl, v);
+  }
+  uint32_t entry = __shfl_up(incl, 1);
+  if (l == 0) entry = NONE;
+  entry = min(entry, limit0);
+  // first stop: event 2s = before slot s (N <= rounds so far), 2s + 1 = after slot s (all inliers)
+  uint32_t ev = NONE;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t slot = (uint32_t)(4 * l + k);
+    if (ev == NONE) {
+      if (!(entry > done0 + slot)) ev = 2 * slot;
+      else if (cnt[k] == (uint32_t)P.n) ev = 2 * slot + 1;
     }
-    const uint32_t count = P.hyp_count[slot];
-    done_rounds++;
-    if (count == (uint32_t)P.n) {      // :127-131: everything is an inlier
-      for (int k = 0; k < 9; k++) st->best_F[k] = P.hyp_F[(size_t)slot * 9 + k];
-      best = count;
-      finished = true;
-      break;
-    }
-    limit = min(limit, P.rounds_needed[count]);
-    if (count > best) {                // :138-141
-      for (int k = 0; k < 9; k++) st->best_F[k] = P.hyp_F[(size_t)slot * 9 + k];
-      best = count;
+    entry = min(entry, need[k]);
+  }
+  const uint32_t first_ev = wave_min_u32(ev);
+  const bool stop_before = first_ev != NONE && (first_ev & 1u) == 0;
+  const bool stop_after = first_ev != NONE && (first_ev & 1u) != 0;
+  const uint32_t consumed = first_ev == NONE ? (uint32_t)ROUNDS_PER_LAUNCH : (stop_after ? first_ev / 2 + 1 : first_ev / 2);
+  const uint32_t lowered_by = stop_after ? consumed - 1 : consumed;   // the all-inlier slot leaves N alone
+  // N afterwards, and the largest count among the consumed slots at its first occurrence
+  uint32_t lim = NONE;
+  unsigned long long top = 0;   // count << 32 | (NONE - slot): larger count first, then the earlier slot
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t slot = (uint32_t)(4 * l + k);
+    if (slot < lowered_by) lim = min(lim, need[k]);
+    if (slot < consumed) {
+      const unsigned long long key = ((unsigned long long)cnt[k] << 32) | (unsigned long long)(NONE - slot);
+      top = key > top ? key : top;
     }
   }
-  if (!(limit > done_rounds)) finished = true;
-  st->rounds_limit = limit;
-  st->rounds_done = done_rounds;
-  st->best_count = best;
-  st->done = finished ? 1u : 0u;
-  if (!finished) atomicAdd(unfinished, 1u);
+  lim = min(wave_min_u32(lim), limit0);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long u = __shfl_xor(top, o);
+    top = u > top ? u : top;
+  }
+  const uint32_t top_count = (uint32_t)(top >> 32), top_slot = NONE - (uint32_t)(top & 0xFFFFFFFFull);
+  const bool replaced = consumed > 0 && top_count > best0;
+  const uint32_t done_rounds = done0 + consumed;
+  const bool finished = stop_before || stop_after || !(lim > done_rounds);
+  if (replaced && l < 9) st->best_F[l] = P.hyp_F[(size_t)top_slot * 9 + l];
+  if (l == 0) {
+    st->rounds_limit = lim;
+    st->rounds_done = done_rounds;
+    st->best_count = replaced ? top_count : best0;
+    st->done = finished ? 1u : 0u;
+    if (!finished) atomicAdd(unfinished, 1u);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

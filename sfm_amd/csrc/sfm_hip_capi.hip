@@ -185,6 +185,9 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   if (ctx->cascade_counters) (void)hipFree(ctx->cascade_counters);
   for (DevBuf& b : ctx->geometry_buffers)
     if (b.p) (void)hipFree(b.p);
+  if (ctx->geometry_readback) (void)hipStreamDestroy(ctx->geometry_readback);
+  for (hipEvent_t e : ctx->geometry_events)
+    if (e) (void)hipEventDestroy(e);
   for (auto e : ctx->cascade_timing) (void)hipEventDestroy(e);
   for (auto& t : ctx->timed) {
     (void)hipEventDestroy(t.start);

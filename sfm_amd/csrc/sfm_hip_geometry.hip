@@ -102,7 +102,7 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   if ((rc = grown(ctx, 7, (size_t)total, &d_flags.p))) return rc;
   if ((rc = grown(ctx, 8, (size_t)n_live * 4, &d_counts.p))) return rc;
   if ((rc = grown(ctx, 9, (size_t)n_live * sizeof(GeoPair), &d_pairs.p))) return rc;
-  if ((rc = grown(ctx, 10, 4, &d_unfinished.p))) return rc;
+  if ((rc = grown(ctx, 10, 4 * 16, &d_unfinished.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(d_lhs.p, lhs_xy, (size_t)total * 16, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_rhs.p, rhs_xy, (size_t)total * 16, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_tables.p, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, st));
@@ -140,18 +140,32 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   HIP_TRY(ctx, hipMemcpyAsync(d_pairs.p, pairs.data(), pairs.size() * sizeof(GeoPair), hipMemcpyHostToDevice, st));
 
   const GeoPair* dp = (const GeoPair*)d_pairs.p;
-  for (uint32_t first = 0; first < MAX_ROUNDS; first += ROUNDS_PER_LAUNCH) {
-    HIP_TRY(ctx, hipMemsetAsync(d_unfinished.p, 0, 4, st));
+  // Launch k + 1 is queued before launch k's "unfinished" counter has been read: when pairs are
+  // left it starts without waiting for the host, and when none are its kernels return at once.
+  constexpr int MAX_LAUNCHES = MAX_ROUNDS / ROUNDS_PER_LAUNCH;
+  static_assert(MAX_LAUNCHES <= 16, "one event and one counter per launch");
+  if (!ctx->geometry_readback) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->geometry_readback, hipStreamNonBlocking));
+  for (int k = 0; k < MAX_LAUNCHES; k++)
+    if (!ctx->geometry_events[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->geometry_events[k], hipEventDisableTiming));
+  HIP_TRY(ctx, hipMemsetAsync(d_unfinished.p, 0, 4 * MAX_LAUNCHES, st));
+  auto queue_launch = [&](int k) -> int {
+    const uint32_t first = (uint32_t)k * ROUNDS_PER_LAUNCH;
     hipLaunchKernelGGL(k_geo_fit, dim3(ROUNDS_PER_LAUNCH / HYP_THREADS, (unsigned)n_live), dim3(HYP_THREADS), 0, st, dp, first);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_geo_count, dim3((unsigned)n_live), dim3(ROUNDS_PER_LAUNCH), 0, st, dp, first);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)((n_live + 63) / 64)), dim3(64), 0, st, dp, n_live,
-                       (uint32_t*)d_unfinished.p);
+    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)n_live), dim3(64), 0, st, dp, n_live, (uint32_t*)d_unfinished.p + k);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->geometry_events[k], st));
+    return SFM_HIP_OK;
+  };
+  if ((rc = queue_launch(0))) return rc;
+  for (int k = 0; k < MAX_LAUNCHES; k++) {
+    if (k + 1 < MAX_LAUNCHES && (rc = queue_launch(k + 1))) return rc;
     uint32_t unfinished = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&unfinished, d_unfinished.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->geometry_readback, ctx->geometry_events[k], 0));
+    HIP_TRY(ctx, hipMemcpyAsync(&unfinished, (uint32_t*)d_unfinished.p + k, 4, hipMemcpyDeviceToHost, ctx->geometry_readback));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->geometry_readback));
     if (unfinished == 0) break;
   }
   hipLaunchKernelGGL(k_geo_classify, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_live), dim3(256), 0, st, dp);
