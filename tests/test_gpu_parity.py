@@ -340,3 +340,18 @@ def test_profiling_times_one_launch_in_eight(matcher):
     assert st["distance_launches"] == 3            # launches 0, 8 and 16
     assert st["distance_ms"] > 0.0
     assert st["distance_flop"] == 3 * 2.0 * 512 * 512 * 128
+
+
+def test_nan_and_inf_in_descriptors_fall_back_to_the_exact_scan(matcher):
+    """A NaN or an infinity in an image makes its norms useless for the candidate bounds: every query
+    of the pair is then answered by the exact full scan, and the result is still the oracle's (a
+    candidate at a NaN distance never wins a '<', brute_force_matcher.cc:26-33)."""
+    A, B, _ = synth.make_pair(700, 900, 300, seed=11)
+    B = B.copy()
+    B[5, 17] = np.nan
+    B[77, :] = np.nan
+    B[300, 3] = np.inf
+    matcher.reset_stats()
+    for cross in (False, True):
+        check_pair(matcher, A, B, cross)
+    assert matcher.stats()["rescanned_queries"] >= 700
