@@ -200,6 +200,28 @@ __device__ __forceinline__ double epipolar_line_error(double x, double y, double
   return (num * num) * deno;
 }
 
+// `epipolar_line_error(...) > 3.84` (ransac.hpp:118), decided exactly but usually without the two
+// divisions (about fifteen instructions each): with hardware reciprocals the error is known to a
+// relative 1e-3 at the very worst, which settles every match whose error is not within that of
+// 3.84; the others, and anything out of the ordinary range (a NaN fails every comparison and lands
+// there too), take the exact route.
+__device__ __forceinline__ bool epipolar_error_exceeds(double x, double y, double xp, double yp, const double (&F)[9]) {
+#pragma clang fp contract(off)
+  const double lx = (F[0] * x + F[1] * y) + F[2];
+  const double ly = (F[3] * x + F[4] * y) + F[5];
+  const double rx = (F[0] * xp + F[3] * yp) + F[6];
+  const double ry = (F[1] * xp + F[4] * yp) + F[7];
+  const double rz = (F[2] * xp + F[5] * yp) + F[8];
+  const double num = (rx * x + ry * y) + rz;
+  const double s1 = lx * lx + ly * ly, s2 = rx * rx + ry * ry, nn = num * num;
+  const double approx = nn * (__builtin_amdgcn_rcp(s1) + __builtin_amdgcn_rcp(s2));
+  const bool tame = fmin(s1, s2) > 1e-200 && fmax(s1, s2) < 1e200;
+  if (tame && approx > 3.84 * 1.001) return true;
+  if (tame && approx < 3.84 * 0.999) return false;
+  const double deno = 1.0 / s1 + 1.0 / s2;
+  return nn * deno > 3.84;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 256 rounds of every unfinished pair, in two kernels because they want opposite things from the
 // register file: the fit keeps two matrices in registers and runs one wavefront per SIMD, the
@@ -268,7 +290,9 @@ __global__ __launch_bounds__(ROUNDS_PER_LAUNCH) void k_geo_count(const GeoPair* 
   for (int k = 0; k < 9; k++) F[k] = live ? P.hyp_F[(size_t)slot * 9 + k] : 0.0;
 #pragma unroll
   for (int k = 0; k < SAMPLE; k++) idx[k] = live ? P.hyp_idx[(size_t)slot * SAMPLE + k] : -1;
-  // ransac.hpp:112-124: the sample is in unexamined, everything else unless its error exceeds 3.84
+  // ransac.hpp:112-124: the sample is in unexamined, everything else unless its error exceeds 3.84.
+  // Every match is measured here, the sample's eight among them; what those eight contributed is
+  // taken off again below (asking "is this one of the eight" per match costs more than the eight).
   uint32_t count = SAMPLE;
   for (int i0 = 0; i0 < n; i0 += COUNT_TILE) {
     const int m = min(COUNT_TILE, n - i0);
@@ -280,15 +304,23 @@ __global__ __launch_bounds__(ROUNDS_PER_LAUNCH) void k_geo_count(const GeoPair* 
     if (live) {
       for (int t = 0; t < m; t++) {
         const double2 a = tile_l[t], b = tile_r[t];
-        const int i = i0 + t;
-        bool in_sample = false;
-#pragma unroll
-        for (int k = 0; k < SAMPLE; k++) in_sample |= idx[k] == i;
-        const double err = epipolar_line_error(a.x, a.y, b.x, b.y, F);
-        count += (!in_sample && !(err > 3.84)) ? 1u : 0u;
+        count += epipolar_error_exceeds(a.x, a.y, b.x, b.y, F) ? 0u : 1u;
       }
     }
     __syncthreads();
+  }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < SAMPLE; k++) {
+      bool repeated = false;   // an index drawn twice is one match
+#pragma unroll
+      for (int j = 0; j < k; j++) repeated |= idx[j] == idx[k];
+      if (!repeated && idx[k] >= 0 && idx[k] < n) {
+        const double2 a = reinterpret_cast<const double2*>(P.lhs)[idx[k]];
+        const double2 b = reinterpret_cast<const double2*>(P.rhs)[idx[k]];
+        count -= epipolar_error_exceeds(a.x, a.y, b.x, b.y, F) ? 0u : 1u;
+      }
+    }
   }
   if (live) P.hyp_count[slot] = count;
 }
