@@ -152,6 +152,32 @@ def replication_check(m, rank, world, local_rank, barrier, n_images=64):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def batched_leg(m, engine, n_pairs=64, calls=24):
+    """The same pair handed to the library 64 at a time (how the C++ matcher class calls it on a whole
+    image set): chunks then span all columns, the per-workgroup set-up is paid once per eight times
+    the work, and the re-rank and compaction of one call run beside the next call's distance kernel."""
+    import numpy as np
+    m.set_engine(engine)
+    pairs = np.array([[0, 1]] * n_pairs, np.int64)
+    for _ in range(4):
+        m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+    m.sync()
+    m.set_profiling(True)
+    m.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+    m.sync()
+    elapsed = time.perf_counter() - t0
+    st = m.stats()
+    m.set_profiling(False)
+    value = calls * n_pairs / elapsed
+    return {"pairs_per_call": n_pairs, "calls": calls, "engine": engine, "value": value, "unit": "pairs/s",
+            "ms_per_pair": elapsed / (calls * n_pairs) * 1e3,
+            "frac_of_fp32_mfma_peak_end_to_end": value * 2.0 * N_FEATURES * N_FEATURES * 128 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "roofline": roofline(st, engine, None)}
+
+
 def roofline(st, engine, traffic):
     """Distance kernel against the matrix-instruction peak of the type it multiplies in.
 
@@ -331,6 +357,8 @@ def main():
                 "frac_of_fp32_mfma_peak_end_to_end": o_value * flop_per_launch / (PEAK_FP32_MFMA_TFLOPS * 1e12),
                 "rescanned_queries_per_pair": o_st["rescanned_queries"] / max(1, o_st["pairs"]),
                 "matches_equal_main_engine": bool(same), "roofline": roofline(o_st, other, None)}
+        if world == 1 and not args.no_other_engine and args.pairs_per_step == 1:
+            line["batched"] = batched_leg(m, args.engine)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, B, got)
         if world == 1 and not args.no_cascade:
