@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--replication-check", action="store_true",
                     help="N > 1: also time host uploads against the RCCL all-gather of a descriptor set "
                          "(outside the timed region; adds collectives to the run, hence opt-in)")
+    ap.add_argument("--no-batched", action="store_true",
+                    help="do not time the 64-pairs-per-call leg after the main run")
     ap.add_argument("--no-cascade", action="store_true",
                     help="do not time the cascade-hash matcher after the main run")
     ap.add_argument("--untimed-pass", action="store_true",
@@ -357,7 +359,7 @@ def main():
                 "frac_of_fp32_mfma_peak_end_to_end": o_value * flop_per_launch / (PEAK_FP32_MFMA_TFLOPS * 1e12),
                 "rescanned_queries_per_pair": o_st["rescanned_queries"] / max(1, o_st["pairs"]),
                 "matches_equal_main_engine": bool(same), "roofline": roofline(o_st, other, None)}
-        if world == 1 and not args.no_other_engine and args.pairs_per_step == 1:
+        if world == 1 and not args.no_batched and args.pairs_per_step == 1:
             line["batched"] = batched_leg(m, args.engine)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, B, got)

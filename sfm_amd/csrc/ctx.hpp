@@ -43,17 +43,18 @@ struct TimedLaunch {
   double flop;
 };
 
-// A lane = one stream with its own work space; nothing is shared between two batches.
+// A lane = one work space and the stream its batch's short kernels run on; no memory is shared
+// between two batches.
 // Brute-force matcher: every batch's distance kernel goes to the context's distance stream, one
 // after the other with nothing in between, and its short tail (re-rank, compaction, copies) to the
-// stream of the batch's lane, which waits for that distance kernel through the event that rides on
-// its dispatch packet.  The tail of batch b then runs beside the distance kernel of batch b + 1
+// tail stream of the batch's lane (two tail streams, lanes take them in turn), which waits for that
+// distance kernel through the event that rides on its dispatch packet.  The tail of batch b then runs beside the distance kernel of batch b + 1
 // (its workgroups fit in what a distance workgroup leaves of a compute unit).  A lane is taken
 // again only after its previous tail has finished, which the host checks (a wait on the distance
 // stream would put a packet, and several microseconds, between two distance kernels).
 // Cascade-hash matcher: a batch's kernels all run on its lane's stream, lanes 0 and 1 in turn.
 struct Lane {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // one of the context's tail streams (not owned): lane i uses stream i % N_TAIL_STREAMS
   // grow-only device work space
   DevBuf tables_dev, rowpart, colpart, best, out_dev;
   // cascade-hash matcher: pair table, per-query slots + list counters (all zeros between batches),
@@ -78,6 +79,10 @@ struct Lane {
 
 constexpr int N_LANES = 4;
 constexpr int N_CASCADE_LANES = 2;
+// A process has four hardware queues (GPU_MAX_HW_QUEUES) and streams beyond that share them, in
+// order: a tail stream on the distance stream's hardware queue would put its kernels between two
+// distance kernels again.  Distance stream + upload stream + two tail streams = four.
+constexpr int N_TAIL_STREAMS = 2;
 
 }  // namespace sfm_host
 
@@ -87,6 +92,7 @@ struct sfm_hip_ctx {
   int next_lane = 0;
   int next_cascade_lane = 0;
   hipStream_t distance_stream = nullptr;   // all launches of the distance kernel, in order
+  hipStream_t tail_streams[sfm_host::N_TAIL_STREAMS] = {};
   unsigned launches_since_timed = 0;       // profiling: distance launches since the last timed one
   std::map<int64_t, sfm_host::Image> images;
   std::string last_error;
@@ -136,10 +142,8 @@ inline int fail(sfm_hip_ctx* ctx, int code, const std::string& msg) {
 
 inline int sync_all(sfm_hip_ctx* ctx) {
   if (ctx->distance_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->distance_stream));
-  for (Lane& l : ctx->lanes) {
-    HIP_TRY(ctx, hipStreamSynchronize(l.stream));
-    l.tail_pending = false;
-  }
+  for (hipStream_t t : ctx->tail_streams) HIP_TRY(ctx, hipStreamSynchronize(t));
+  for (Lane& l : ctx->lanes) l.tail_pending = false;
   return SFM_HIP_OK;
 }
 

@@ -141,8 +141,10 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   e = hipSetDevice(device);
+  for (hipStream_t& t : ctx->tail_streams)
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&t, hipStreamNonBlocking);
+  for (int i = 0; i < N_LANES; i++) ctx->lanes[i].stream = ctx->tail_streams[i % N_TAIL_STREAMS];
   for (Lane& l : ctx->lanes) {
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
     if (e == hipSuccess && !ctx->upload_stream) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
     for (int s = 0; s < 2 && e == hipSuccess; s++) e = hipEventCreateWithFlags(&l.stage_free[s], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&l.distance_done);
@@ -164,8 +166,8 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->distance_stream) (void)hipStreamSynchronize(ctx->distance_stream);
-  for (Lane& l : ctx->lanes)
-    if (l.stream) (void)hipStreamSynchronize(l.stream);
+  for (hipStream_t t : ctx->tail_streams)
+    if (t) (void)hipStreamSynchronize(t);
   for (auto& kv : ctx->images) free_image(kv.second);
   for (Lane& l : ctx->lanes) {
     for (DevBuf* b : {&l.tables_dev, &l.rowpart, &l.colpart, &l.best, &l.out_dev, &l.cascade_tables, &l.cascade_slots, &l.cascade_lists})
@@ -176,8 +178,9 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
     }
     if (l.distance_done) (void)hipEventDestroy(l.distance_done);
     if (l.tail_done) (void)hipEventDestroy(l.tail_done);
-    if (l.stream) (void)hipStreamDestroy(l.stream);
   }
+  for (hipStream_t t : ctx->tail_streams)
+    if (t) (void)hipStreamDestroy(t);
   if (ctx->distance_stream) (void)hipStreamDestroy(ctx->distance_stream);
   if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
   if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
