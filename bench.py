@@ -242,18 +242,15 @@ def main():
     # SFM_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL group, barriers, max over ranks)
     # even with one rank: a rehearsal for machines with a single GPU
     dist_on = world > 1 or os.environ.get("SFM_BENCH_FORCE_DIST") == "1"
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+    torch.cuda.set_device(local_rank if dist_on else 0)
 
     import sfm_amd
     from sfm_amd import synth
 
+    # The matcher's context first, the process group after it: a process has four hardware queues and
+    # streams are given them in order of creation.  The context's four streams must not share one
+    # (a tail kernel queued in front of a distance kernel delays it); RCCL's streams, idle during the
+    # timed region, may share as they like.
     m = sfm_amd.Matcher(local_rank if dist_on else 0)
     m.set_engine(args.engine)
     A, B, truth = synth.make_pair(N_FEATURES, N_FEATURES, PLANTED, seed=2024 + rank)
@@ -262,6 +259,14 @@ def main():
     m.upload(1, B)
     upload_s = time.perf_counter() - t0
     pairs = np.array([[0, 1]] * args.pairs_per_step, np.int64)
+    for _ in range(4):   # every stream of the context has been used once (queues are bound at first use)
+        m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+    m.sync()
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist_on:
@@ -276,12 +281,16 @@ def main():
             for _ in range(20):
                 m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
             m.sync()
-        m.set_profiling(not args.no_profile_events)
-        for _ in range(args.warmup):
+        # The W warm-up steps are still running while the ranks meet at the barrier (with a few more
+        # behind them to cover it): a barrier on an idle GPU lets its clocks drop again.
+        for _ in range(args.warmup + (40 if dist_on else 0)):
             m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+        if dist_on:
+            dist.barrier()
         m.sync()
+        m.set_profiling(not args.no_profile_events)
         m.reset_stats()
-        barrier()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)

@@ -142,7 +142,8 @@ inline int fail(sfm_hip_ctx* ctx, int code, const std::string& msg) {
 
 inline int sync_all(sfm_hip_ctx* ctx) {
   if (ctx->distance_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->distance_stream));
-  for (hipStream_t t : ctx->tail_streams) HIP_TRY(ctx, hipStreamSynchronize(t));
+  for (hipStream_t t : ctx->tail_streams)
+    if (t) HIP_TRY(ctx, hipStreamSynchronize(t));
   for (Lane& l : ctx->lanes) l.tail_pending = false;
   return SFM_HIP_OK;
 }
