@@ -355,3 +355,31 @@ def test_nan_and_inf_in_descriptors_fall_back_to_the_exact_scan(matcher):
     for cross in (False, True):
         check_pair(matcher, A, B, cross)
     assert matcher.stats()["rescanned_queries"] >= 700
+
+
+def test_contexts_come_and_go():
+    """Forty contexts created, used and destroyed in turn (streams, events and work space go with
+    them), and three alive at once: the last one still answers like the first."""
+    import sfm_amd
+    A, B, _ = synth.make_pair(300, 400, 120, seed=21)
+    exp = oracle.match_pair(A, B, 0.8, True)
+    for _ in range(40):
+        m = sfm_amd.Matcher(0)
+        m.upload(0, A)
+        m.upload(1, B)
+        (got,) = m.match_pairs([(0, 1)], 0.8, True)
+        m.close()
+    assert_same(got, exp)
+    ms = [sfm_amd.Matcher(0) for _ in range(3)]
+    try:
+        for m in ms:
+            m.upload(0, A)
+            m.upload(1, B)
+        outs = [m.match_pairs_async([(0, 1)], 0.8, True) for m in ms]
+        for m, (cnt, lhs, rhs, dist) in zip(ms, outs):
+            m.sync()
+            c = int(cnt[0])
+            assert_same((lhs[0, :c].astype(np.int64), rhs[0, :c].astype(np.int64), dist[0, :c].copy()), exp)
+    finally:
+        for m in ms:
+            m.close()
