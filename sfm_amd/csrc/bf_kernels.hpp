@@ -52,10 +52,10 @@ constexpr int NCAND = 4;             // candidates re-ranked exactly per query
 constexpr int ROWPART_FIELDS = 2 * NCAND + 1;  // keys, column indices, bound key
 
 constexpr int LDS_STAGE_BYTES = SN * DIM * 4;                 // 64 KiB
-constexpr int LDS_COLBUF_WORDS = 4 * 4 * 3 * 64;              // per parity: wave, tile, k, lane (both half-waves)
+constexpr int LDS_COLBUF_WORDS = 4 * 4 * 2 * 64;              // per parity: wave, tile, entry, lane (both half-waves)
 constexpr int LDS_OFF_COLBUF = 2 * LDS_STAGE_BYTES;
 constexpr int LDS_TOTAL = LDS_OFF_COLBUF + 2 * LDS_COLBUF_WORDS * 4;
-constexpr int ROWBUF_STRIDE = 97;    // 96 keys per row + 1 word so that rows fall on different banks
+constexpr int ROWBUF_STRIDE = 65;    // 64 keys per row + 1 word so that rows fall on different banks
 
 // Row of the 256-row block that a column-list key's low bits name.
 __host__ __device__ inline uint32_t col_key_row(uint32_t lo) {
@@ -124,6 +124,12 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
 // Insert x into the ascending triple (a <= b <= c), dropping the largest of the four.
 __device__ __forceinline__ void insert3(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t x) {
   c = med3u(b, c, x);
+  b = med3u(a, b, x);
+  a = a < x ? a : x;
+}
+
+// Insert x into the ascending pair (a <= b), dropping the largest of the three.
+__device__ __forceinline__ void insert2(uint32_t& a, uint32_t& b, uint32_t x) {
   b = med3u(a, b, x);
   a = a < x ? a : x;
 }
@@ -305,9 +311,10 @@ __device__ __forceinline__ void lds_wait() {
 }
 
 // Private row lists of one lane for one 32-row tile: per accumulator register (= row)
-// the three smallest keys over the columns this lane has seen.
+// the two smallest keys over the columns this lane has seen.  The second one doubles as the bound
+// on everything the lane saw and did not keep.
 struct LaneLists {
-  uint32_t r0[16], r1[16], r2[16];
+  uint32_t r0[16], r1[16];
 };
 
 // Pin sixteen values to this program point (an empty asm that "modifies" them): the optimizer
@@ -391,13 +398,12 @@ __device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32
 // Fold one finished accumulator tile into the lane's row lists and column list.
 // tv = column-tile number (row key low bits); RT = which of the wave's two row tiles.
 template <int RT>
-__device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLists& L, uint32_t& cl0, uint32_t& cl1,
-                                          uint32_t& cl2) {
+__device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLists& L, uint32_t& cl0, uint32_t& cl1) {
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
     const uint32_t gb = __float_as_uint(acc[reg]);
-    insert3(L.r0[reg], L.r1[reg], L.r2[reg], (gb & ROW_MASK) | tv);
-    insert3(cl0, cl1, cl2, (gb & COL_MASK) | (uint32_t)(RT * 32 + reg));
+    insert2(L.r0[reg], L.r1[reg], (gb & ROW_MASK) | tv);
+    insert2(cl0, cl1, (gb & COL_MASK) | (uint32_t)(RT * 32 + reg));
   }
 }
 
@@ -422,21 +428,20 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
   pair_steps<ENGINE, TOFF, CT % 3, (CT < 3), CT>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X, feed,
                                                  yvoff);
 
-  uint32_t cl0 = SENT, cl1 = SENT, cl2 = SENT;
+  uint32_t cl0 = SENT, cl1 = SENT;
 #ifdef SFM_ABLATE_FOLD
   asm volatile("" ::"v"(acc0), "v"(acc1));   // diagnostic build: accumulators stay live, lists untouched
 #else
-  tile_fold<0>(acc0, tv, L0, cl0, cl1, cl2);
-  tile_fold<1>(acc1, tv, L1, cl0, cl1, cl2);
+  tile_fold<0>(acc0, tv, L0, cl0, cl1);
+  tile_fold<1>(acc1, tv, L1, cl0, cl1);
 #endif
   // every lane parks its list (over its half-wave's 32 rows of the column); the eight lists of a
   // column -- four waves, two half-waves -- are merged once per stage
   cb[0] = cl0 | lowc;
   cb[64] = cl1 | lowc;
-  cb[128] = cl2 | lowc;
   // keep the epilogue where it is written: next to this tile pair, not sunk to the end of the stage
-  anchor16(L0.r0); anchor16(L0.r1); anchor16(L0.r2);
-  anchor16(L1.r0); anchor16(L1.r1); anchor16(L1.r2);
+  anchor16(L0.r0); anchor16(L0.r1);
+  anchor16(L1.r0); anchor16(L1.r1);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -449,7 +454,7 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
 // even step (four matrix instructions), one per odd step (two), the remaining eight afterwards.
 // ---------------------------------------------------------------------------
 struct FoldState {
-  uint32_t cl0, cl1, cl2;   // the column list being built for the tile that is folded
+  uint32_t cl0, cl1;   // the column list being built for the tile that is folded
 };
 
 // Element E of a finished tile pair: E < 16 is register E of the first row tile's accumulator.
@@ -459,8 +464,8 @@ __device__ __forceinline__ void fold_elem(const f32x16& p0, const f32x16& p1, ui
   constexpr int RT = E >> 4, REG = E & 15;
   const uint32_t gb = __float_as_uint(RT == 0 ? p0[REG] : p1[REG]);
   LaneLists& L = RT == 0 ? L0 : L1;
-  insert3(L.r0[REG], L.r1[REG], L.r2[REG], (gb & ROW_MASK) | tv);
-  insert3(f.cl0, f.cl1, f.cl2, (gb & COL_MASK) | (uint32_t)(RT * 32 + REG));
+  insert2(L.r0[REG], L.r1[REG], (gb & ROW_MASK) | tv);
+  insert2(f.cl0, f.cl1, (gb & COL_MASK) | (uint32_t)(RT * 32 + REG));
 }
 template <int... E>
 __device__ __forceinline__ void fold_elems(std::integer_sequence<int, E...>, const f32x16& p0, const f32x16& p1,
@@ -519,7 +524,7 @@ __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x
   for (int i = 0; i < 16; i++) zero[i] = 0.0f;
   acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
-  FoldState f{SENT, SENT, SENT};
+  FoldState f{SENT, SENT};
   (pipe_step<CT, S, FOLD, (CT < 3), (S % 4 == 1 ? 4 * CT + S / 4 : -1)>(acc0, acc1, a0, a1, b, X, feed, yvoff, p0, p1, tvp,
                                                                         L0, L1, f),
    ...);
@@ -528,31 +533,40 @@ __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x
     fold_elems(std::integer_sequence<int, 24, 25, 26, 27, 28, 29, 30, 31>{}, p0, p1, tvp, L0, L1, f);
     cbp[0] = f.cl0 | lowc;
     cbp[64] = f.cl1 | lowc;
-    cbp[128] = f.cl2 | lowc;
   }
 }
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
-// Merge the eight lists of one column of a finished stage (four waves x two half-waves) and store
-// the result.  Lane (c, hh) of the wave takes column c of the wave's column tile and the lists of
-// waves 2hh and 2hh+1; the two halves are then merged with v_permlane32_swap.  cbaddr is the LDS
-// byte address of the first of the lane's twelve entries; it is made opaque to the optimizer so
-// that the reads stay "one register + immediate offset".
+// Merge the eight lists of one column of a finished stage (four waves x two half-waves, two entries
+// each) and store the three smallest keys.  The third one is also the bound on everything the
+// block left out for this column, so it is lowered to the smallest SECOND entry of the eight lists
+// (what a list dropped is not below its second entry) -- which is one of the sixteen keys itself:
+// when it undercuts the third smallest it is the second smallest, and the column's third plane
+// then repeats the second.  Lane (c, hh) of the wave takes column c of the wave's column tile and
+// the lists of waves 2hh and 2hh+1; the two halves are then merged with v_permlane32_swap.  cbaddr
+// is the LDS byte address of the first of the lane's eight entries; it is made opaque to the
+// optimizer so that the reads stay "one register + immediate offset".
 __device__ __forceinline__ void stage_columns_out(uint32_t cbaddr, int hh, __amdgpu_buffer_rsrc_t dst, uint32_t voff,
                                                   uint32_t soff, uint32_t plane_bytes) {
   asm volatile("" : "+v"(cbaddr));
   const lds_u32* cb = (const lds_u32*)cbaddr;
-  uint32_t k0 = cb[0], k1 = cb[64], k2 = cb[128];
+  uint32_t k0 = cb[0], k1 = cb[64], k2 = SENT;
+  uint32_t second = k1;
 #pragma unroll
   for (int li = 1; li < 4; li++) {       // (wave, half-wave) = (0,1), (1,0), (1,1) relative to the first
-#pragma unroll
-    for (int k = 0; k < 3; k++) insert3(k0, k1, k2, cb[(li >> 1) * 4 * 3 * 64 + (li & 1) * 32 + k * 64]);
+    const uint32_t a = cb[(li >> 1) * 4 * 2 * 64 + (li & 1) * 32];
+    const uint32_t b = cb[(li >> 1) * 4 * 2 * 64 + (li & 1) * 32 + 64];
+    insert3(k0, k1, k2, a);
+    insert3(k0, k1, k2, b);
+    second = second < b ? second : b;
   }
-  const uint32_t p0 = other_half(k0), p1 = other_half(k1), p2 = other_half(k2);
+  const uint32_t p0 = other_half(k0), p1 = other_half(k1), p2 = other_half(k2), ps = other_half(second);
   insert3(k0, k1, k2, p0);
   insert3(k0, k1, k2, p1);
   insert3(k0, k1, k2, p2);
+  second = second < ps ? second : ps;
+  k2 = k2 < second ? k2 : second;
   if (hh == 0) {
     __builtin_amdgcn_raw_buffer_store_b32(k0, dst, voff, soff, 0);
     __builtin_amdgcn_raw_buffer_store_b32(k1, dst, voff, soff + plane_bytes, 0);
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 
   LaneLists L0, L1;
 #pragma unroll
-  for (int i = 0; i < 16; i++) L0.r0[i] = L0.r1[i] = L0.r2[i] = L1.r0[i] = L1.r1[i] = L1.r2[i] = SENT;
+  for (int i = 0; i < 16; i++) L0.r0[i] = L0.r1[i] = L1.r0[i] = L1.r1[i] = SENT;
 
   const uint32_t lowc = (uint32_t)((w << 6) | (h << 4));
   // LDS byte address of this lane's row inside a column tile, for each of the 8 chunk positions it
@@ -716,7 +730,7 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   const uint32_t colvoff = (uint32_t)((32 * w + r) * 4);
   const uint32_t colbuf_addr =
       (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + LDS_OFF_COLBUF +
-      (uint32_t)((((2 * h) * 4 + w) * 3 * 64 + r) * 4);   // wave 2h, column tile w, entry 0, lane r of half-wave 0
+      (uint32_t)((((2 * h) * 4 + w) * 2 * 64 + r) * 4);   // wave 2h, column tile w, entry 0, lane r of half-wave 0
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // stage 0 landed
@@ -745,29 +759,28 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
                         plane_bytes);
     uint32_t tv = (uint32_t)(4 * gg);
     asm volatile("" : "+v"(tv));   // a VGPR, so that the row key is one v_and_or_b32
-    uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 3) * 64 + l;
+    uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 2) * 64 + l;
     f32x4 b[3];
     const uint32_t (&X)[8] = u == 0 ? X0 : X1;
     if constexpr (ENGINE == ENGINE_F32) {
-      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 192, feed, yvoff);
-      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 192, feed, yvoff);
-      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 192, feed, yvoff);
-      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 192, feed, yvoff);
+      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 128, feed, yvoff);
+      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 128, feed, yvoff);
+      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 128, feed, yvoff);
+      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 128, feed, yvoff);
     } else {
       constexpr auto STEPS = std::make_integer_sequence<int, 16>{};
       f32x16 e0, e1, o0, o1;   // accumulators of the even and of the odd column tiles
       pipe_tile<0, false>(STEPS, e0, e1, a0, a1, an0, an1, bn[0], b, X, feed, yvoff, o0, o1, tv, L0, L1, lowc, cb);
-      pipe_tile<1, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[1], b, X, feed, yvoff, e0, e1, tv + 0, L0, L1, lowc, cb + 0 * 192);
-      pipe_tile<2, true>(STEPS, e0, e1, a0, a1, an0, an1, bn[2], b, X, feed, yvoff, o0, o1, tv + 1, L0, L1, lowc, cb + 1 * 192);
-      pipe_tile<3, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[3], b, X, feed, yvoff, e0, e1, tv + 2, L0, L1, lowc, cb + 2 * 192);
+      pipe_tile<1, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[1], b, X, feed, yvoff, e0, e1, tv + 0, L0, L1, lowc, cb + 0 * 128);
+      pipe_tile<2, true>(STEPS, e0, e1, a0, a1, an0, an1, bn[2], b, X, feed, yvoff, o0, o1, tv + 1, L0, L1, lowc, cb + 1 * 128);
+      pipe_tile<3, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[3], b, X, feed, yvoff, e0, e1, tv + 2, L0, L1, lowc, cb + 2 * 128);
       // the stage's last tile has no matrix work left to hide behind
-      FoldState f{SENT, SENT, SENT};
+      FoldState f{SENT, SENT};
       fold_elems(std::make_integer_sequence<int, 32>{}, o0, o1, tv + 3, L0, L1, f);
-      cb[3 * 192 + 0] = f.cl0 | lowc;
-      cb[3 * 192 + 64] = f.cl1 | lowc;
-      cb[3 * 192 + 128] = f.cl2 | lowc;
-      anchor16(L0.r0); anchor16(L0.r1); anchor16(L0.r2);
-      anchor16(L1.r0); anchor16(L1.r1); anchor16(L1.r2);
+      cb[3 * 128 + 0] = f.cl0 | lowc;
+      cb[3 * 128 + 64] = f.cl1 | lowc;
+      anchor16(L0.r0); anchor16(L0.r1);
+      anchor16(L1.r0); anchor16(L1.r1);
     }
     // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
     // compiler does not always drain it for __syncthreads(), so wait explicitly.
@@ -791,18 +804,19 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
     const int R = 64 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    uint32_t* d0 = rowbuf + R * ROWBUF_STRIDE + r * 3;
+    uint32_t* d0 = rowbuf + R * ROWBUF_STRIDE + r * 2;
     uint32_t* d1 = d0 + 32 * ROWBUF_STRIDE;
-    d0[0] = L0.r0[reg]; d0[1] = L0.r1[reg]; d0[2] = L0.r2[reg];
-    d1[0] = L1.r0[reg]; d1[1] = L1.r1[reg]; d1[2] = L1.r2[reg];
+    d0[0] = L0.r0[reg]; d0[1] = L0.r1[reg];
+    d1[0] = L1.r0[reg]; d1[1] = L1.r1[reg];
   }
   __syncthreads();
   {
-    // Row tid: 32 sorted triples.  The five smallest keys of all 96 come from the lists whose
-    // head is among the five smallest heads, so rank the heads first and then add the tails of
+    // Row tid: 32 sorted pairs.  The five smallest keys of all 64 come from the lists whose head
+    // is among the five smallest heads, so rank the heads first and then add the second entries of
     // those five lists only.  While ranking, a key carries (lane, entry) in its low bits in place
     // of the tile number, so that five v_med3/v_min per insertion suffice (no index to drag
-    // along); the winners' full keys are read back from LDS afterwards.
+    // along); the winners' full keys are read back from LDS afterwards.  What a lane left out is
+    // not below its second entry: the smallest of those bounds everything outside the 64 keys.
     const uint32_t* src = rowbuf + tid * ROWBUF_STRIDE;
     uint32_t m0 = SENT, m1 = SENT, m2 = SENT, m3 = SENT, m4 = SENT;
     auto put = [&](uint32_t x) {
@@ -815,23 +829,20 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     uint32_t lanebound = SENT;
 #pragma unroll 8
     for (int p = 0; p < 32; p++) {
-      put((src[p * 3] & ROW_MASK) | (uint32_t)p);
-      const uint32_t k2 = src[p * 3 + 2];
-      lanebound = lanebound < k2 ? lanebound : k2;
+      put((src[p * 2] & ROW_MASK) | (uint32_t)p);
+      const uint32_t k1 = src[p * 2 + 1];
+      lanebound = lanebound < k1 ? lanebound : k1;
     }
     const uint32_t hp[5] = {m0 & 31u, m1 & 31u, m2 & 31u, m3 & 31u, m4 & 31u};
 #pragma unroll
-    for (int e = 0; e < 5; e++) {
-      put((src[hp[e] * 3 + 1] & ROW_MASK) | hp[e] | 32u);
-      put((src[hp[e] * 3 + 2] & ROW_MASK) | hp[e] | 64u);
-    }
-    // low bits of a ranked key: lane (5 bits), entry in that lane's triple (2 bits)
+    for (int e = 0; e < 5; e++) put((src[hp[e] * 2 + 1] & ROW_MASK) | hp[e] | 32u);
+    // low bits of a ranked key: lane (5 bits), entry in that lane's pair (1 bit)
     const uint32_t mk[4] = {m0, m1, m2, m3};
     uint32_t fullkey[4], lane[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       lane[e] = mk[e] & 31u;
-      fullkey[e] = src[lane[e] * 3 + ((mk[e] >> 5) & 3u)];
+      fullkey[e] = src[lane[e] * 2 + ((mk[e] >> 5) & 1u)];
     }
     const uint32_t fifth = m4 == SENT ? SENT : (m4 & ROW_MASK);   // value bits only: never above the real key
     const uint32_t bound = lanebound < fifth ? lanebound : fifth;
