@@ -241,8 +241,13 @@ __global__ __launch_bounds__(256) void k_split(const float* __restrict__ x, cons
 // In the 32x32 accumulator layout lane (c, h) holds column c and rows
 // (reg&3) + 8(reg>>2) + 4h.  Column minima are therefore lane-local; row minima
 // are spread over the 32 lanes of a half-wave, so every lane keeps a private
-// 3-entry list per row over the columns it sees (c, c+32, ...) and the lists are
-// merged once, at the end of the chunk.
+// 2-entry list per row over the columns it sees (c, c+32, ...) and the lists are
+// merged once, at the end of the chunk.  Two entries, not three: a list's second entry is
+// also the bound on what the list dropped, and that is all the re-rank needs from it (it
+// decides nearly every query from the two smallest keys and a bound) -- six vector
+// instructions per accumulator element instead of eight.  The price: a query whose two
+// nearest columns share a list AND whose ratio test is too close for the keys to call
+// cannot be proven complete from the lists and takes the exact full scan.
 // ---------------------------------------------------------------------------
 // Wave w fills rows 32w .. 32w+31 of a stage: 16 LDS-DMA instructions of 1 KiB (2 rows) each.
 // Addressing is a buffer descriptor over the chunk's columns + a per-lane byte offset (voff: the
@@ -1027,7 +1032,7 @@ constexpr int RR_SQ_STRIDE = 132;    // words per row of squares (128 + 4: confl
 // PP = 0: the variant for launches that do not fill the chip (a single pair).  Step B without the
 // transposition through LDS: one lane per (query, candidate) reads both rows itself and adds up in
 // index order.  Its workgroups need 3.4 KiB of LDS and 104 registers, which is what a compute unit
-// has left beside a workgroup of k_distance_topk (152 KiB of LDS, one wave of 360 registers per
+// has left beside a workgroup of k_distance_topk (144 KiB of LDS, one wave of 320 registers per
 // SIMD), so the re-rank of one pair can be resident while the next pair's distance kernel runs.
 // (It does not come for free then: beside the fp32 matrix instructions every vector instruction of
 // the re-rank still takes its turn on the SIMD; beside the fp16 ones it does overlap.)
