@@ -455,8 +455,8 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
 // v_mfma_f32_32x32x16_f16 -- unlike beside the fp32 matrix instructions -- vector instructions
 // execute concurrently, at half their usual rate (tools/mfma_valu.hip, tools/split_step_bench.hip).
 // So while the matrix instructions of column tile CT run into one pair of accumulators, the
-// finished pair of column tile CT-1 is folded into the lists: two accumulator elements per
-// even step (four matrix instructions), one per odd step (two), the remaining eight afterwards.
+// finished pair of column tile CT-1 is folded into the lists: three accumulator elements per
+// even step (four matrix instructions, six vector instructions per element), one per odd step (two).
 // ---------------------------------------------------------------------------
 struct FoldState {
   uint32_t cl0, cl1;   // the column list being built for the tile that is folded
@@ -497,14 +497,17 @@ __device__ __forceinline__ void pipe_step(f32x16& acc0, f32x16& acc1, const f32x
   if constexpr ((S & 1) == 0) {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S]), frag, acc1, 0, 0, 0);
-    if constexpr (FOLD) fold_elem<3 * (S / 2)>(p0, p1, tvp, L0, L1, f);
+    if constexpr (FOLD) {
+      fold_elem<4 * (S / 2)>(p0, p1, tvp, L0, L1, f);
+      fold_elem<4 * (S / 2) + 1>(p0, p1, tvp, L0, L1, f);
+    }
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S + 1]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S + 1]), frag, acc1, 0, 0, 0);
-    if constexpr (FOLD) fold_elem<3 * (S / 2) + 1>(p0, p1, tvp, L0, L1, f);
+    if constexpr (FOLD) fold_elem<4 * (S / 2) + 2>(p0, p1, tvp, L0, L1, f);
   } else {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S - 1]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S - 1]), frag, acc1, 0, 0, 0);
-    if constexpr (FOLD) fold_elem<3 * (S / 2) + 2>(p0, p1, tvp, L0, L1, f);
+    if constexpr (FOLD) fold_elem<4 * (S / 2) + 3>(p0, p1, tvp, L0, L1, f);
   }
 #ifndef SFM_ABLATE_GLDS
   if constexpr (PIECE >= 0) stage_load_piece<PIECE>(feed.src, feed.ldsbuf, feed.w, yvoff, feed.sbase);
@@ -534,8 +537,7 @@ __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x
                                                                         L0, L1, f),
    ...);
   if constexpr (FOLD) {
-    // the eight elements that found no room above, then the tile's column lists are complete
-    fold_elems(std::integer_sequence<int, 24, 25, 26, 27, 28, 29, 30, 31>{}, p0, p1, tvp, L0, L1, f);
+    // all thirty-two elements went in beside the matrix instructions: the tile's column lists are complete
     cbp[0] = f.cl0 | lowc;
     cbp[64] = f.cl1 | lowc;
   }
