@@ -318,7 +318,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     plans[p].Y = &iy->second;
   }
 
-  int done = 0, rc0 = 0;
+  int done = 0;
   while (done < n_pairs) {
     // ---- choose the batch: as many pairs as fit the work-space budget
     int remaining = n_pairs - done;
@@ -343,7 +343,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       L.tail_pending = false;
     }
     if (L.half_queued) {   // an earlier call failed between this lane's distance kernel and its tail
-      if ((rc0 = sync_all(ctx))) return rc0;
+      if (int rc_sync = sync_all(ctx)) return rc_sync;
       L.half_queued = false;
     }
 
