@@ -383,3 +383,28 @@ def test_contexts_come_and_go():
     finally:
         for m in ms:
             m.close()
+
+
+def test_two_nearest_in_one_lane_list_and_ratio_at_the_threshold(matcher):
+    """The distance kernel keeps two candidates per lane and row; here the two nearest columns of a
+    query sit 32 apart (the same lane's list) and their ratio straddles 0.8 within parts per million,
+    so neither the keys nor the lists can settle the query: it must come out right by the exact scan."""
+    rng = np.random.default_rng(8)
+    n = 256
+    A = synth.rootsift_rows(n, 223)
+    B = synth.rootsift_rows(64 * n, 224)
+    for i in range(n):
+        e1 = rng.standard_normal(128)
+        e1 /= np.linalg.norm(e1)
+        e2 = rng.standard_normal(128)
+        e2 -= e2.dot(e1) * e1
+        e2 /= np.linalg.norm(e2)
+        delta = 0.05 + 0.1 * rng.random()
+        eps = (rng.random() - 0.5) * 2e-5
+        B[64 * i] = (A[i] + delta * 0.8 * (1 + eps) * e1).astype(np.float32)
+        B[64 * i + 32] = (A[i] + delta * e2).astype(np.float32)
+    matcher.reset_stats()
+    l, r, d = check_pair(matcher, A, B, False)
+    assert 0.2 * n < len(l) < 0.8 * n
+    check_pair(matcher, A, B, True)
+    assert matcher.stats()["rescanned_queries"] > 0
