@@ -408,3 +408,26 @@ def test_two_nearest_in_one_lane_list_and_ratio_at_the_threshold(matcher):
     assert 0.2 * n < len(l) < 0.8 * n
     check_pair(matcher, A, B, True)
     assert matcher.stats()["rescanned_queries"] > 0
+
+
+def test_two_nearest_in_one_column_list_and_ratio_at_the_threshold(matcher):
+    """The mirror image for the reverse direction: the two nearest ROWS of a second-image query are
+    neighbours in the first image (the same half-wave's column list) with a ratio at the threshold."""
+    rng = np.random.default_rng(9)
+    n = 256
+    Y = synth.rootsift_rows(n, 323)
+    X = synth.rootsift_rows(64 * n, 324)
+    for i in range(n):
+        e1 = rng.standard_normal(128)
+        e1 /= np.linalg.norm(e1)
+        e2 = rng.standard_normal(128)
+        e2 -= e2.dot(e1) * e1
+        e2 /= np.linalg.norm(e2)
+        delta = 0.05 + 0.1 * rng.random()
+        eps = (rng.random() - 0.5) * 2e-5
+        X[64 * i] = (Y[i] + delta * 0.8 * (1 + eps) * e1).astype(np.float32)
+        X[64 * i + 1] = (Y[i] + delta * e2).astype(np.float32)
+    matcher.reset_stats()
+    l, r, d = check_pair(matcher, X, Y, True)
+    assert 0.1 * n < len(l) < 0.9 * n
+    assert matcher.stats()["rescanned_queries"] > 0
