@@ -51,9 +51,11 @@ constexpr unsigned PROFILE_EVERY = 8;   // profiling: one distance launch in thi
 // Order of a pair's nrb x nch blocks (row block, chunk) for a launch whose first block of this pair
 // sits at a position congruent to first_pos modulo 8.  The grid is cut gr x gc = 8 ways, choosing the
 // cut that needs the fewest bytes of rows plus columns per rectangle; position p then takes the next
-// block of rectangle (first_pos + p) % 8, or of the next rectangle that still has blocks.
-void xcd_order(int nrb, int nch, int chunk_cols, int first_pos, std::vector<std::pair<int, int>>& out) {
-  out.clear();
+// block of rectangle (first_pos + p) % 8, or of the next rectangle that still has blocks.  Inside a
+// rectangle the blocks go chunk by chunk, row blocks ascending.  sink(row block, chunk) receives the
+// blocks in launch order; nothing is allocated.
+template <class Sink>
+void xcd_order(int nrb, int nch, int chunk_cols, int first_pos, Sink&& sink) {
   int best_gr = 1;
   long best_cost = -1;
   for (int gr = 1; gr <= N_XCD; gr *= 2) {
@@ -65,20 +67,22 @@ void xcd_order(int nrb, int nch, int chunk_cols, int first_pos, std::vector<std:
     }
   }
   const int gr = best_gr, gc = N_XCD / gr;
-  std::vector<std::pair<int, int>> region[N_XCD];
+  int r0[N_XCD], nr[N_XCD], c0[N_XCD];
+  size_t size[N_XCD], cursor[N_XCD] = {0};
   for (int i = 0; i < gr; i++)
     for (int j = 0; j < gc; j++) {
-      const int r0 = (int)((long)nrb * i / gr), r1 = (int)((long)nrb * (i + 1) / gr);
-      const int c0 = (int)((long)nch * j / gc), c1 = (int)((long)nch * (j + 1) / gc);
-      for (int c = c0; c < c1; c++)
-        for (int rb = r0; rb < r1; rb++) region[i * gc + j].emplace_back(rb, c);
+      const int x = i * gc + j;
+      r0[x] = (int)((long)nrb * i / gr);
+      nr[x] = (int)((long)nrb * (i + 1) / gr) - r0[x];
+      c0[x] = (int)((long)nch * j / gc);
+      size[x] = (size_t)nr[x] * (size_t)((int)((long)nch * (j + 1) / gc) - c0[x]);
     }
-  size_t cursor[N_XCD] = {0};
   const size_t total = (size_t)nrb * nch;
   for (size_t p = 0; p < total; p++) {
     int x = (int)((first_pos + p) % N_XCD);
-    for (int tries = 0; tries < N_XCD && cursor[x] >= region[x].size(); tries++) x = (x + 1) % N_XCD;
-    out.push_back(region[x][cursor[x]++]);
+    for (int tries = 0; tries < N_XCD && cursor[x] >= size[x]; tries++) x = (x + 1) % N_XCD;
+    const size_t k = cursor[x]++;
+    sink(r0[x] + (int)(k % (size_t)nr[x]), c0[x] + (int)(k / (size_t)nr[x]));
   }
 }
 
@@ -89,7 +93,10 @@ hipEvent_t get_event(sfm_hip_ctx* ctx) {
     return e;
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  if (hipEventCreate(&e) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
   return e;
 }
 
@@ -412,7 +419,6 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     uint32_t* bp = (uint32_t*)L.best.p;
     size_t nb_i = 0;
     double flop = 0.0;
-    std::vector<std::pair<int, int>> order;
     for (int k = 0; k < count; k++) {
       const PairPlan& pl = plans[done + k];
       PairDev& d = hp[k];
@@ -447,9 +453,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
         // laid out so that position p of the launch holds a block of rectangle p % 8: an XCD then
         // pulls only its rectangle's rows and columns through its L2 instead of nearly everything.
         const int nrb = pl.X->n_pad / BM, nch = pl.nchunks;
-        xcd_order(nrb, nch, pl.chunk_cols, (int)(nb_i % N_XCD), order);
-        for (const std::pair<int, int>& rc : order) {
-          const int rb = rc.first, c = rc.second;
+        xcd_order(nrb, nch, pl.chunk_cols, (int)(nb_i % N_XCD), [&](int rb, int c) {
           const int col0 = c * pl.chunk_cols;
           BlockDev& b = hb[nb_i++];
           b.pair = k;
@@ -460,7 +464,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
           b.xrows = ctx->engine == SFM_HIP_ENGINE_F16X3
                         ? (const void*)(pl.X->split + (size_t)rb * BM * 256)
                         : (const void*)(pl.X->d + (size_t)rb * BM * DIM);
-        }
+        });
         flop += 2.0 * pl.X->n * (double)pl.Y->n * DIM;
       }
     }
@@ -490,10 +494,17 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
           ctx->engine == SFM_HIP_ENGINE_F16X3 ? k_distance_topk<ENGINE_F16X3> : k_distance_topk<ENGINE_F32>;
       hipEvent_t finished = L.distance_done;
       L.half_queued = true;
+      TimedLaunch tl{};
       if (ctx->profiling && ctx->launches_since_timed++ % PROFILE_EVERY == 0) {
-        TimedLaunch tl{};
         tl.start = get_event(ctx);
         tl.stop = get_event(ctx);
+        if (!tl.start || !tl.stop) {   // no events to be had: this launch runs untimed, like its neighbours
+          if (tl.start) ctx->event_pool.push_back(tl.start);
+          if (tl.stop) ctx->event_pool.push_back(tl.stop);
+          tl.start = tl.stop = nullptr;
+        }
+      }
+      if (tl.start) {
         tl.flop = flop;
         hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, tl.start, tl.stop, 0, dp, db);
         const hipError_t e = hipGetLastError();
