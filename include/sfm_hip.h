@@ -114,6 +114,29 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
                         int cross_check, int32_t* out_counts, int32_t* out_lhs_idx,
                         int32_t* out_rhs_idx, float* out_dist, int64_t out_stride);
 
+/* The same match for ONE pair, for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (whose
+ * matcher allocates per task, brute_force_matcher.cc:47-52).  The call allocates and frees nothing,
+ * on the device or through the HIP runtime: its work space (candidate lists, per-query results, the
+ * table of workgroups) is a fixed array of 8 MiB that is part of the library's GPU code, one copy per
+ * GPU, held until the process ends.  Limits and rules:
+ *   - both images hold at most SFM_HIP_NOALLOC_MAX_ROWS descriptors; larger ones are refused
+ *     (SFM_HIP_ERR_INVALID), use sfm_hip_match_pairs for them;
+ *   - out_lhs_idx / out_rhs_idx / out_dist have room for as many entries as the first image has
+ *     descriptors, out_count for one; the kernels write them directly, so they must be pinned host
+ *     memory (sfm_hip_host_alloc) or device memory; out_dist may be NULL;
+ *   - the results are those of sfm_hip_match_pairs for the same pair, bit for bit;
+ *   - asynchronous like sfm_hip_match_pairs (outputs are valid after sfm_hip_sync); calls on one
+ *     context run one after the other, in call order, also relative to sfm_hip_match_pairs calls that
+ *     write the same outputs;
+ *   - every call on a GPU uses that GPU's one array: calls through two contexts of the same GPU
+ *     (or from two processes' worth of threads on one context) that overlap in time race.  Calls
+ *     on different GPUs do not interfere. */
+#define SFM_HIP_NOALLOC_MAX_ROWS 8192
+int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t second_image, double ratio,
+                               int cross_check, int32_t* out_count, int32_t* out_lhs_idx,
+                               int32_t* out_rhs_idx, float* out_dist);
+
 /* How the distance stage forms the 128-term products a.b of ||a||^2 + ||b||^2 - 2 a.b
  * (the candidates it proposes are always re-ranked with the reference's exact fp32
  * arithmetic, src/metric.hpp:15-22, and proven complete, so the matches are the same

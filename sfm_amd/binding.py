@@ -15,7 +15,7 @@ EXPORTS = (
     "sfm_hip_upload_image", "sfm_hip_drop_image", "sfm_hip_drop_all_images", "sfm_hip_image_size",
     "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
     "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats", "sfm_hip_set_engine",
-    "sfm_hip_upload_image_device",
+    "sfm_hip_upload_image_device", "sfm_hip_match_pair_noalloc",
     "sfm_hip_cascade_set_projection", "sfm_hip_cascade_column_sums", "sfm_hip_cascade_hash_images",
     "sfm_hip_cascade_get_hashes", "sfm_hip_cascade_match_pairs", "sfm_hip_cascade_reference_projection",
     "sfm_hip_cascade_image_order", "sfm_hip_cascade_prepare", "sfm_hip_cascade_get_stats",
@@ -75,6 +75,7 @@ def library():
     lib.sfm_hip_drop_all_images.argtypes = [vp]
     lib.sfm_hip_image_size.argtypes = [vp, i64, ctypes.POINTER(i32)]
     lib.sfm_hip_match_pairs.argtypes = [vp, vp, i32, ctypes.c_double, ctypes.c_int, vp, vp, vp, vp, i64]
+    lib.sfm_hip_match_pair_noalloc.argtypes = [vp, i64, i64, ctypes.c_double, ctypes.c_int, vp, vp, vp, vp]
     lib.sfm_hip_sync.argtypes = [vp]
     lib.sfm_hip_host_alloc.argtypes = [ctypes.c_size_t]
     lib.sfm_hip_host_alloc.restype = vp
@@ -234,6 +235,17 @@ class Matcher:
 
     def sync(self):
         self._check(self._lib.sfm_hip_sync(self._h), "sfm_hip_sync")
+
+    def pinned(self, shape, dtype):
+        """A pinned host array from the library's allocator (free() it, or leave it to the process)."""
+        return _Pinned(self._lib, shape, dtype)
+
+    def match_pair_noalloc_async(self, first, second, ratio, cross_check, cnt, lhs, rhs, dist=None):
+        """sfm_hip_match_pair_noalloc on caller-provided _Pinned outputs (valid after sync())."""
+        self._check(self._lib.sfm_hip_match_pair_noalloc(self._h, int(first), int(second), float(ratio),
+                                                         int(bool(cross_check)), cnt.ptr, lhs.ptr, rhs.ptr,
+                                                         dist.ptr if dist is not None else None),
+                    "sfm_hip_match_pair_noalloc")
 
     def match_pairs(self, pairs, ratio=0.8, cross_check=True):
         """[(lhs_idx int64, rhs_idx int64, dist float32)] per pair, as the reference stores them."""

@@ -97,6 +97,8 @@ struct sfm_hip_ctx {
   std::map<int64_t, sfm_host::Image> images;
   std::string last_error;
   unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
+  unsigned char* noalloc_scratch = nullptr;     // this device's copy of the fixed work space of
+                                                // sfm_hip_match_pair_noalloc (an array in the code object)
 
   int engine = SFM_HIP_ENGINE_F32;
   bool profiling = false;

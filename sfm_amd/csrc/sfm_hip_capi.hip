@@ -115,6 +115,60 @@ int fold_timed(sfm_hip_ctx* ctx) {
   return SFM_HIP_OK;
 }
 
+// ---- work space of sfm_hip_match_pair_noalloc -------------------------------------------------
+// One array per GPU, part of the code object: it exists from the moment the library is loaded on a
+// device until the process ends.  Host code never uses this name as an address; sfm_hip_ctx_create
+// asks the runtime for the array's address on the context's device and everything goes through that.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)8 << 20;
+constexpr int NOALLOC_MAX_BLOCKS = 1024;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+// Launch order of the distance workgroups as (row block, chunk) bytes: travels as a kernel argument.
+struct NoallocOrder {
+  uint8_t row_block[NOALLOC_MAX_BLOCKS];
+  uint8_t chunk[NOALLOC_MAX_BLOCKS];
+};
+
+// Writes the pair record and the table of distance workgroups into the work space (what
+// sfm_hip_match_pairs builds in pinned memory and copies over).
+__global__ __launch_bounds__(256) void k_noalloc_tables(PairDev pair, NoallocOrder order, int n_blocks, int engine,
+                                                        PairDev* __restrict__ out_pair, BlockDev* __restrict__ out_blocks) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) *out_pair = pair;
+  if (t >= n_blocks) return;
+  const int rb = order.row_block[t], c = order.chunk[t];
+  const int col0 = c * pair.chunk_cols;
+  BlockDev b;
+  b.pair = 0;
+  b.row0 = rb * BM;
+  b.col0 = col0;
+  b.ncols = min(pair.chunk_cols, pair.nb_pad - col0);
+  b.chunk = c;
+  b.pad_ = 0;
+  b.xrows = engine == ENGINE_F16X3 ? (const void*)(pair.xh + (size_t)rb * BM * 256)
+                                   : (const void*)(pair.x + (size_t)rb * BM * DIM);
+  out_blocks[t] = b;
+}
+
+// Address through which a kernel on the current device can write caller memory that is pinned host
+// memory or device memory; nullptr for anything else.
+void* device_view_of_output(void* p) {
+  if (!p) return nullptr;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) return p;
+  if (a.type != hipMemoryTypeHost) return nullptr;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return d;
+}
+
 }  // namespace
 
 extern "C" {
@@ -160,6 +214,9 @@ int sfm_hip_ctx_create(int device, sfm_hip_ctx** out_ctx) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->distance_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->rescanned_dev, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(ctx->rescanned_dev, 0, sizeof(unsigned long long));
+  // the address of this device's copy of the work-space array (every GPU holds its own)
+  if (e == hipSuccess) e = hipGetSymbolAddress((void**)&ctx->noalloc_scratch, HIP_SYMBOL(scratch));
+  if (e == hipSuccess && !ctx->noalloc_scratch) e = hipErrorInvalidSymbol;
   if (e != hipSuccess) {
     std::string msg = std::string("context set-up: ") + hipGetErrorString(e);
     sfm_hip_ctx_destroy(ctx);
@@ -589,6 +646,125 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     ctx->stats.queries += n_queries;
     done += count;
   }
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t second_image, double ratio,
+                               int cross_check, int32_t* out_count, int32_t* out_lhs_idx, int32_t* out_rhs_idx,
+                               float* out_dist) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (!out_count || !out_lhs_idx || !out_rhs_idx) return fail(ctx, SFM_HIP_ERR_INVALID, "null output buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto ix = ctx->images.find(first_image);
+  auto iy = ctx->images.find(second_image);
+  if (ix == ctx->images.end() || iy == ctx->images.end())
+    return fail(ctx, SFM_HIP_ERR_INVALID, "the pair names an image that was not uploaded");
+  if (ix->second.n > SFM_HIP_NOALLOC_MAX_ROWS || iy->second.n > SFM_HIP_NOALLOC_MAX_ROWS)
+    return fail(ctx, SFM_HIP_ERR_INVALID,
+                "sfm_hip_match_pair_noalloc takes images of at most " + std::to_string(SFM_HIP_NOALLOC_MAX_ROWS) +
+                    " descriptors (got " + std::to_string(ix->second.n) + " and " + std::to_string(iy->second.n) +
+                    "): its work space has a fixed size; use sfm_hip_match_pairs");
+  int32_t* k_count = (int32_t*)device_view_of_output(out_count);
+  int32_t* k_lhs = (int32_t*)device_view_of_output(out_lhs_idx);
+  int32_t* k_rhs = (int32_t*)device_view_of_output(out_rhs_idx);
+  float* k_dist = (float*)device_view_of_output(out_dist);
+  if (!k_count || !k_lhs || !k_rhs || (out_dist && !k_dist))
+    return fail(ctx, SFM_HIP_ERR_INVALID,
+                "sfm_hip_match_pair_noalloc writes its outputs from the GPU: they must be pinned host memory "
+                "(sfm_hip_host_alloc) or device memory");
+
+  PairPlan pl{};
+  pl.X = &ix->second;
+  pl.Y = &iy->second;
+  const int nrb = pl.X->n_pad / BM;
+  plan_chunks(pl, nrb, ctx->n_cu);
+  const bool has_blocks = pl.X->n > 0 && pl.Y->n > 0;
+  const int n_blocks = has_blocks ? nrb * pl.nchunks : 0;
+
+  // work space: pair record | block table | distances nobody asked for | results per query | lists
+  unsigned char* base = ctx->noalloc_scratch;
+  size_t at = 0;
+  PairDev* d_pair = (PairDev*)(base + at);
+  at += align_up(sizeof(PairDev), 256);
+  BlockDev* d_blocks = (BlockDev*)(base + at);
+  at += sizeof(BlockDev) * NOALLOC_MAX_BLOCKS;
+  float* d_dist = (float*)(base + at);
+  at += (size_t)SFM_HIP_NOALLOC_MAX_ROWS * sizeof(float);
+  uint32_t* bp = (uint32_t*)(base + at);
+  at += align_up(pl.best_words * 4, 256);
+  uint32_t* rp = (uint32_t*)(base + at);
+  at += align_up(pl.rowpart_words * 4, 256);
+  uint32_t* cp = (uint32_t*)(base + at);
+  at += align_up(pl.colpart_words * 4, 256);
+  if (at > NOALLOC_SCRATCH_BYTES || n_blocks > NOALLOC_MAX_BLOCKS || nrb > 256 || pl.nchunks > 256)
+    return fail(ctx, SFM_HIP_ERR_INVALID, "sfm_hip_match_pair_noalloc: the pair does not fit the fixed work space");
+
+  PairDev d{};
+  d.x = pl.X->d;
+  d.xn = pl.X->norms;
+  d.y = pl.Y->d;
+  d.yn = pl.Y->norms;
+  d.rowpart = rp;
+  d.colpart = cp;
+  d.fwd_best = (int32_t*)bp;
+  d.fwd_dist = (float*)(bp + pl.X->n_pad);
+  d.rev_best = (int32_t*)(bp + 2 * (size_t)pl.X->n_pad);
+  d.rev_dist = (float*)(bp + 2 * (size_t)pl.X->n_pad + pl.Y->n_pad);
+  d.na = pl.X->n;
+  d.nb = pl.Y->n;
+  d.na_pad = pl.X->n_pad;
+  d.nb_pad = pl.Y->n_pad;
+  d.nchunks = pl.nchunks;
+  d.chunk_cols = pl.chunk_cols;
+  d.out_slot = 0;
+  d.xh = pl.X->split;
+  d.yh = pl.Y->split;
+  d.xscale = pl.X->scale;
+  d.yscale = pl.Y->scale;
+  NoallocOrder order;
+  int nb_i = 0;
+  if (has_blocks)
+    xcd_order(nrb, pl.nchunks, pl.chunk_cols, 0, [&](int rb, int c) {
+      order.row_block[nb_i] = (uint8_t)rb;
+      order.chunk[nb_i] = (uint8_t)c;
+      nb_i++;
+    });
+
+  // Everything runs on the distance stream, in order: calls of this entry point share one work space
+  // and must not overlap.  Tails of earlier sfm_hip_match_pairs calls run on other streams; this
+  // call's results must land after theirs.
+  hipStream_t ds = ctx->distance_stream;
+  for (Lane& other : ctx->lanes)
+    if (other.tail_pending) HIP_TRY(ctx, hipStreamWaitEvent(ds, other.tail_done, 0));
+  const int eng = ctx->engine == SFM_HIP_ENGINE_F16X3 ? ENGINE_F16X3 : ENGINE_F32;
+  hipLaunchKernelGGL(k_noalloc_tables, dim3((unsigned)std::max(1, (n_blocks + 255) / 256)), dim3(256), 0, ds, d, order,
+                     n_blocks, eng, d_pair, d_blocks);
+  HIP_TRY(ctx, hipGetLastError());
+  if (n_blocks) {
+    void (*kernel)(const PairDev*, const BlockDev*) =
+        eng == ENGINE_F16X3 ? k_distance_topk<ENGINE_F16X3> : k_distance_topk<ENGINE_F32>;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, (const PairDev*)d_pair,
+                       (const BlockDev*)d_blocks);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    // an empty image: no candidate lists were written, so give the re-rank empty ones
+    HIP_TRY(ctx, hipMemsetAsync(rp, 0xFF, pl.rowpart_words * 4, ds));
+    HIP_TRY(ctx, hipMemsetAsync(cp, 0xFF, pl.colpart_words * 4, ds));
+  }
+  const int max_q = cross_check ? std::max(pl.X->n, pl.Y->n) : pl.X->n;
+  if (max_q > 0) {
+    const dim3 grid((max_q + RR_QUERIES - 1) / RR_QUERIES, 1, cross_check ? 2 : 1);
+    if ((size_t)grid.x * grid.z >= (size_t)4 * ctx->n_cu)
+      hipLaunchKernelGGL(k_rerank<64>, grid, dim3(256), 0, ds, (const PairDev*)d_pair, ratio, eng, ctx->rescanned_dev);
+    else
+      hipLaunchKernelGGL(k_rerank<0>, grid, dim3(256), 0, ds, (const PairDev*)d_pair, ratio, eng, ctx->rescanned_dev);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_cross_compact, dim3(1), dim3(1024), 0, ds, (const PairDev*)d_pair, cross_check ? 1 : 0, k_count,
+                     k_lhs, k_rhs, k_dist ? k_dist : d_dist, (int64_t)SFM_HIP_NOALLOC_MAX_ROWS);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->stats.pairs += 1;
+  ctx->stats.queries += (uint64_t)pl.X->n + (uint64_t)pl.Y->n;
   return SFM_HIP_OK;
 }
 
