@@ -5,14 +5,27 @@ A step = one pass of the hot path over one image pair of the headline
 configuration (8192 x 8192 descriptors of 128 floats, ratio 0.8, cross-check):
 distance/top-k kernel, exact re-rank, cross-check, compaction, copy of the
 compact match list to pinned host memory.  Descriptors are resident in HBM
-before the timed region starts.  With --gpus N every rank matches its own
-pairs (pairs are independent: no collective on the data path), so the value is
-the sum over ranks ("weak" scaling).
+before the timed region starts.
+
+With --gpus N > 1 the ranks run the SHARDED JOB of BASELINE.json configs[3]
+(exhaustive matching of 500 synthetic images x 8192 features): the pair list of
+ExhaustivePairBuilder is partitioned by the library (sfm_hip_partition_pairs:
+2-D blocks of the pair triangle of equal cost), every rank uploads only its
+block's images, and a step is one 64-pair call of sfm_hip_match_pairs on the
+next pairs of the rank's shard -- the way the C++ matcher class drives the
+library.  Pairs are independent, so there is no collective on the data path and
+per-GPU work per step is fixed ("weak" scaling); value = pairs all ranks matched
+/ the slowest rank's time.  After the timed region the same ranks run the whole
+job once, uploads, matching and the gather of all match lists to rank 0 timed
+separately ("whole_job"), and time the two ways of replicating a descriptor set
+("replication").
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+
+import numpy as np
 import os
 import sys
 import time
@@ -27,25 +40,39 @@ PEAK_FP16_MFMA_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (den
 PEAK_HBM_GBPS = 8000.0          # HBM3E
 
 
+def host_cores():
+    """(threads this process may use, CPUs the machine has).  The first is what a CPU leg runs on:
+    the scheduler affinity of the process, capped by OMP_NUM_THREADS where the box sets a share."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        allowed = min(allowed, int(share))
+    return max(1, allowed), os.cpu_count() or 1
+
+
 def cpu_baseline(A, B, expected):
     """Time the CPU oracle (a port of the reference matcher) on this host.
 
     Sample: one full 8192x8192 pair with cross-check on two threads, which is
     how the reference runs a pair (its ThreadPool has two workers, one per
-    direction); then the same pair on 16 threads.
+    direction); then the same pair on every core this process may use.
     """
     from oracle import oracle
+    cores, machine = host_cores()
     t0 = time.perf_counter()
     l, r, d = oracle.match_pair(A, B, 0.8, True, threads=2)
     t2 = time.perf_counter() - t0
     same = (l.tolist() == expected[0].tolist() and r.tolist() == expected[1].tolist())
     t0 = time.perf_counter()
-    oracle.match_pair(A, B, 0.8, True, threads=16)
-    t16 = time.perf_counter() - t0
+    oracle.match_pair(A, B, 0.8, True, threads=cores)
+    tall = time.perf_counter() - t0
     return {"value": 1.0 / t2, "unit": "pairs/s", "cores": 2, "kind": "port",
             "sample": "one full 8192x8192 pair, ratio 0.8 + cross-check, 2 threads (the reference's pool size)",
             "seconds_per_pair": t2, "matches_equal_gpu": bool(same),
-            "all_cores": {"value": 1.0 / t16, "cores": 16, "seconds_per_pair": t16}}
+            "all_cores": {"value": 1.0 / tall, "cores": cores, "seconds_per_pair": tall, "cpus_of_the_machine": machine}}
 
 
 def cascade_cpu_baseline(images, pairs, got):
@@ -67,7 +94,6 @@ def cascade_leg(m, with_cpu, n_images=32, reps=40):
     a synthetic set with repeated structure, descriptors and hashes resident.  value counts
     back-to-back batches; the roofline figure comes from batches run one at a time between HIP
     events (bytes: the library's count of what a pair has to read at the least)."""
-    import numpy as np
     from sfm_amd import synth
     imgs = synth.make_repetitive_set(n_images, N_FEATURES, 0.5, 2, seed=17, sigma=0.002)
     ids = list(range(100, 100 + n_images))
@@ -126,7 +152,6 @@ def replication_check(m, rank, world, local_rank, barrier, n_images=64):
     """Outside the timed region, N > 1 only: how long it takes to give every GPU a descriptor set
     of n_images x 8192 rows (i) by uploading everything from each rank's host memory and (ii) by
     uploading each rank's share and all-gathering over RCCL/xGMI.  Reported, never fatal."""
-    import numpy as np
     import torch
     import torch.distributed as dist
     from sfm_amd.distributed import replicate_images, shard_bounds
@@ -152,11 +177,143 @@ def replication_check(m, rank, world, local_rank, barrier, n_images=64):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+SET_SEED = 4242
+PAIRS_PER_CALL = 64
+
+
+class SetJob:
+    """An exhaustive matching job over a synthetic scene set (every two images share PLANTED true
+    correspondences), cut for `world` ranks by the library's partition.  Images are generated per
+    rank, only those its shard names."""
+
+    def __init__(self, n_images, rank, world):
+        from sfm_amd import synth
+        from sfm_amd.distributed import exhaustive_pairs, images_of, partition
+        self.n_images, self.rank, self.world = n_images, rank, world
+        self.ids = list(range(n_images))
+        self.rows = {i: N_FEATURES for i in self.ids}
+        self.pairs = exhaustive_pairs(self.ids)
+        self.shards = partition(self.pairs, self.rows, world)
+        self.mine = self.shards[rank]
+        self.need = images_of(self.pairs, self.mine) if len(self.mine) else []
+        self.images_per_rank = [len(images_of(self.pairs, s)) if len(s) else 0 for s in self.shards]
+        pool = synth.scene_pool(PLANTED, SET_SEED)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, host_cores()[0])) as ex:
+            made = list(ex.map(lambda i: synth.scene_image(i, N_FEATURES, pool, SET_SEED), self.need))
+        self.images = dict(zip(self.need, made))
+
+    def upload(self, m):
+        for i in self.need:
+            m.upload(i, self.images[i])
+
+    def batch(self, k):
+        """The k-th 64-pair call of this rank's shard (wrapping round at its end)."""
+        n = len(self.mine)
+        idx = self.mine[(np.arange(PAIRS_PER_CALL) + k * PAIRS_PER_CALL) % n]
+        return self.pairs[idx]
+
+    def run(self, m):
+        """The whole shard through 64-pair calls, two sets of pinned outputs in turn: the GPU matches
+        call b while the host copies the compact lists of call b - 1 out.  Returns (counts, lhs, rhs)."""
+        counts = np.zeros(len(self.mine), np.int32)
+        lhs_parts, rhs_parts = [], []
+
+        def collect(lo, out):
+            cnt, lhs, rhs, _ = out
+            counts[lo:lo + len(cnt)] = cnt
+            for k in range(len(cnt)):
+                lhs_parts.append(lhs[k, :cnt[k]].copy())
+                rhs_parts.append(rhs[k, :cnt[k]].copy())
+
+        prev = None
+        for lo in range(0, len(self.mine), PAIRS_PER_CALL):
+            p = self.pairs[self.mine[lo:lo + PAIRS_PER_CALL]]
+            m.sync()                          # call b - 1 is complete (its outputs are the other set)
+            out = m.match_pairs_async(p, 0.8, True, stride=N_FEATURES)
+            if prev is not None:
+                collect(*prev)
+            prev = (lo, out)
+        m.sync()
+        if prev is not None:
+            collect(*prev)
+        cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0, np.int32)
+        return counts, cat(lhs_parts), cat(rhs_parts)
+
+    def check(self, counts, offsets, lhs, rhs, sample=48):
+        """Planted truth on a sample of pairs spread over the list; totals over all of it."""
+        from sfm_amd import synth
+        n = len(self.pairs)
+        pos = {}
+        found = expected = 0
+        for q in np.linspace(0, n - 1, min(sample, n)).astype(np.int64).tolist():
+            a, b = self.pairs[q].tolist()
+            for i in (a, b):
+                if i not in pos:
+                    pos[i] = synth.scene_positions(i, N_FEATURES, PLANTED, SET_SEED)
+            truth = set(zip(pos[a].tolist(), pos[b].tolist()))
+            got = set(zip(lhs[offsets[q]:offsets[q + 1]].tolist(), rhs[offsets[q]:offsets[q + 1]].tolist()))
+            found += len(got & truth)
+            expected += len(truth)
+        return {"matches": int(counts.sum()), "matches_per_pair_min": int(counts.min()) if n else 0,
+                "matches_per_pair_max": int(counts.max()) if n else 0,
+                "sample_pairs": min(sample, n), "planted_in_sample": expected, "planted_found_in_sample": found}
+
+
+def whole_job_leg(m, job, barrier, max_over_ranks, device, engine):
+    """The whole sharded job once, outside the headline's timed region: uploads of each rank's
+    images, matching of its shard, gather of every pair's (lhs, rhs) lists to rank 0 -- each timed
+    between barriers, the slowest rank counting."""
+    from sfm_amd.distributed import gather_flat
+    m.drop_all()
+    barrier()
+    t0 = time.perf_counter()
+    job.upload(m)
+    m.sync()
+    barrier()
+    t_up = max_over_ranks(time.perf_counter() - t0)
+    m.set_profiling(True)
+    m.reset_stats()
+    t0 = time.perf_counter()
+    counts, lhs, rhs = job.run(m)
+    t_local = time.perf_counter() - t0
+    barrier()
+    t_match = max_over_ranks(time.perf_counter() - t0)
+    st = m.stats()
+    m.set_profiling(False)
+    t0 = time.perf_counter()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        got = gather_flat(counts.reshape(-1, 1), [lhs, rhs], job.shards, job.rank, job.world, device=device)
+    else:
+        off = np.zeros(len(counts) + 1, np.int64)
+        np.cumsum(counts, out=off[1:])
+        assert np.array_equal(job.mine, np.arange(len(job.mine))), "one shard is the list itself"
+        got = (counts.reshape(-1, 1), off, [lhs, rhs])
+    barrier()
+    t_gather = max_over_ranks(time.perf_counter() - t0)
+    if job.rank != 0:
+        return None
+    head, off, (g_lhs, g_rhs) = got
+    n = len(job.pairs)
+    flop = 2.0 * N_FEATURES * N_FEATURES * 128
+    leg = {"workload": "exhaustive matching, %d synthetic images x %d features, %d pairs, ratio 0.8 + cross-check, "
+                       "%d-pair calls of sfm_hip_match_pairs" % (job.n_images, N_FEATURES, n, PAIRS_PER_CALL),
+           "n_gpus": job.world, "pairs": n, "images_uploaded_per_rank": job.images_per_rank,
+           "uploads_s": t_up, "match_s": t_match, "gather_s": t_gather,
+           "pairs_per_s_matching": n / t_match, "pairs_per_s_with_uploads_and_gather": n / (t_up + t_match + t_gather),
+           "value": n / (t_up + t_match + t_gather), "unit": "pairs/s",
+           "frac_of_fp32_mfma_peak_matching": n / t_match * flop / (job.world * PEAK_FP32_MFMA_TFLOPS * 1e12),
+           "rank0_match_s": t_local, "roofline": roofline(st, engine, None),
+           "rescanned_queries": st["rescanned_queries"]}
+    leg.update(job.check(head[:, 0], off, g_lhs, g_rhs))
+    return leg
+
+
 def batched_leg(m, engine, n_pairs=64, calls=24):
     """The same pair handed to the library 64 at a time (how the C++ matcher class calls it on a whole
     image set): chunks then span all columns, the per-workgroup set-up is paid once per eight times
     the work, and the re-rank and compaction of one call run beside the next call's distance kernel."""
-    import numpy as np
     m.set_engine(engine)
     pairs = np.array([[0, 1]] * n_pairs, np.int64)
     for _ in range(4):
@@ -210,14 +367,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pairs-per-step", type=int, default=1,
-                    help="pairs handed to one sfm_hip_match_pairs call (default 1: the headline configuration)")
+                    help="N = 1: pairs handed to one sfm_hip_match_pairs call (default 1: the headline configuration)")
     ap.add_argument("--engine", choices=["f32", "f16x3"], default="f32",
                     help="how the distance kernel forms its products (include/sfm_hip.h)")
     ap.add_argument("--no-other-engine", action="store_true",
                     help="do not time the library's other distance engine after the main run")
-    ap.add_argument("--replication-check", action="store_true",
-                    help="N > 1: also time host uploads against the RCCL all-gather of a descriptor set "
-                         "(outside the timed region; adds collectives to the run, hence opt-in)")
+    ap.add_argument("--no-replication-check", action="store_true",
+                    help="N > 1: do not time host uploads against the RCCL all-gather of a descriptor set "
+                         "(outside the timed region)")
+    ap.add_argument("--set-images", type=int, default=0,
+                    help="images of the exhaustive job: N > 1 default 500 (BASELINE.json configs[3]), "
+                         "N = 1 whole_job leg default 100 (configs[2])")
+    ap.add_argument("--no-whole-job", action="store_true",
+                    help="do not run the whole exhaustive job (uploads + matching + gather) after the timed region")
     ap.add_argument("--no-batched", action="store_true",
                     help="do not time the 64-pairs-per-call leg after the main run")
     ap.add_argument("--no-cascade", action="store_true",
@@ -233,16 +395,16 @@ def main():
                     help="do not bracket the distance kernel with HIP events in the timed region")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # SFM_BENCH_FORCE_DIST=1 takes the multi-rank code path (RCCL group, barriers, max over ranks)
-    # even with one rank: a rehearsal for machines with a single GPU
+    # SFM_BENCH_FORCE_DIST=1 takes the multi-rank code path (sharded job, RCCL group, barriers, max
+    # over ranks, gather) even with one rank: a rehearsal for machines with a single GPU
     dist_on = world > 1 or os.environ.get("SFM_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank if dist_on else 0)
+    device = torch.device("cuda", local_rank if dist_on else 0)
 
     import sfm_amd
     from sfm_amd import synth
@@ -253,38 +415,64 @@ def main():
     # timed region, may share as they like.
     m = sfm_amd.Matcher(local_rank if dist_on else 0)
     m.set_engine(args.engine)
-    A, B, truth = synth.make_pair(N_FEATURES, N_FEATURES, PLANTED, seed=2024 + rank)
     t0 = time.perf_counter()
-    m.upload(0, A)
-    m.upload(1, B)
-    upload_s = time.perf_counter() - t0
-    pairs = np.array([[0, 1]] * args.pairs_per_step, np.int64)
+    if dist_on:
+        job = SetJob(args.set_images or 500, rank, world)
+        if not len(job.mine):
+            raise SystemExit("rank %d has no pairs: fewer pairs than ranks" % rank)
+        setup_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        job.upload(m)
+        upload_s = time.perf_counter() - t0
+        per_step = PAIRS_PER_CALL
+        step_no = [0]
+
+        def step():
+            k = step_no[0]
+            step_no[0] += 1
+            return m.match_pairs_async(job.batch(k), 0.8, True, stride=N_FEATURES)
+    else:
+        A, B, truth = synth.make_pair(N_FEATURES, N_FEATURES, PLANTED, seed=2024 + rank)
+        m.upload(0, A)
+        m.upload(1, B)
+        upload_s = time.perf_counter() - t0
+        per_step = args.pairs_per_step
+        pairs = np.array([[0, 1]] * per_step, np.int64)
+
+        def step():
+            return m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
     for _ in range(4):   # every stream of the context has been used once (queues are bound at first use)
-        m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+        step()
     m.sync()
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region(engine):
+    def max_over_ranks(x):
+        if not dist_on:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_region(engine, step, steps):
         """W untimed steps, then K timed steps between barriers; kernel timing on (one launch in eight)."""
         m.set_engine(engine)
         t_heat = time.perf_counter()
         while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
-            for _ in range(20):
-                m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+            for _ in range(20 if per_step == 1 else 2):
+                step()
             m.sync()
         # The W warm-up steps are still running while the ranks meet at the barrier (with a few more
         # behind them to cover it): a barrier on an idle GPU lets its clocks drop again.
-        for _ in range(args.warmup + (40 if dist_on else 0)):
-            m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+        for _ in range(args.warmup + (40 if dist_on and per_step == 1 else 0)):
+            step()
         if dist_on:
             dist.barrier()
         m.sync()
@@ -292,8 +480,8 @@ def main():
         m.reset_stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+        for _ in range(steps):
+            out = step()
         m.sync()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -301,42 +489,79 @@ def main():
         m.set_profiling(False)
         return out, elapsed, st
 
-    out, elapsed, st = timed_region(args.engine)
+    out, elapsed, st = timed_region(args.engine, step, args.steps)
+    out = tuple(a.copy() for a in out)    # the pinned buffers are the binding's and go when the call shape changes
+    elapsed = max_over_ranks(elapsed)
     # extra information outside the timed region: the same K steps without per-launch kernel timing
-    # (the library then lets consecutive distance kernels overlap at their edges)
     free_rate = None
     if args.untimed_pass:
         m.sync()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
+            step()
         m.sync()
-        free_rate = args.steps * args.pairs_per_step / (time.perf_counter() - t1)
-    replication = None
-    if dist_on and args.replication_check:
-        replication = replication_check(m, rank, world, local_rank, barrier)
+        free_rate = args.steps * per_step / (time.perf_counter() - t1)
 
-    cnt = int(out[0][0])
-    got = (out[1][0, :cnt].astype(np.int64), out[2][0, :cnt].astype(np.int64))
-
+    flop_per_pair = 2.0 * N_FEATURES * N_FEATURES * 128
+    line = None
     if dist_on:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    if rank == 0:
-        total_pairs = args.steps * world * args.pairs_per_step
-        value = total_pairs / elapsed
-        flop_per_launch = 2.0 * N_FEATURES * N_FEATURES * 128
+        # secondary: each rank's single-pair rate (BASELINE.json configs[1]) on the first pair of its shard
+        one = job.pairs[job.mine[:1]]
+        for _ in range(50):
+            m.match_pairs_async(one, 0.8, True, stride=N_FEATURES)
+        m.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            m.match_pairs_async(one, 0.8, True, stride=N_FEATURES)
+        m.sync()
+        rate = args.steps / (time.perf_counter() - t1)
+        rates = torch.zeros(world, dtype=torch.float64, device=device)
+        rates[rank] = rate
+        dist.all_reduce(rates)
+        replication = None if args.no_replication_check else replication_check(m, rank, world, local_rank, barrier)
+        whole = None if args.no_whole_job else whole_job_leg(m, job, barrier, max_over_ranks, device, args.engine)
+        if rank == 0:
+            value = args.steps * per_step * world / elapsed
+            cnt = out[0]
+            line = {
+                "metric": "image pairs/sec, 8k x 8k 128-d descriptors",
+                "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "exhaustive matching of %d synthetic images x %d features (%d pairs, BASELINE.json "
+                                       "configs[3]%s), ratio 0.8 + cross-check, pair list cut into %d shards of equal cost "
+                                       "(2-D blocks of the pair triangle); a step = one %d-pair call of sfm_hip_match_pairs "
+                                       "per GPU on the next pairs of its shard"
+                                       % (job.n_images, N_FEATURES, len(job.pairs),
+                                          "" if job.n_images == 500 else ": a subset", world, PAIRS_PER_CALL),
+                           "engine": args.engine, "pairs_per_step_per_gpu": per_step, "planted_matches": PLANTED,
+                           "matches_last_call_min_max": [int(cnt.min()), int(cnt.max())],
+                           "images_resident_per_gpu": job.images_per_rank,
+                           "parallelism": "pairs sharded over ranks, one process per GPU, no collective on the data path"},
+                "frac_of_fp32_mfma_peak_end_to_end": value / world * flop_per_pair / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                "rescanned_queries_per_pair": st["rescanned_queries"] / max(1, st["pairs"]),
+                "setup_seconds_generating_images": setup_s, "upload_seconds_this_ranks_images": upload_s,
+                "preheat_ms": args.preheat_ms, "pairs_per_s_this_gpu_without_kernel_timing": free_rate,
+                "roofline": roofline(st, args.engine, None),
+                "single_pair_rate_per_gpu": {"unit": "pairs/s", "workload": "BASELINE.json configs[1], one pair per call",
+                                             "per_rank": [float(x) for x in rates.tolist()]},
+            }
+            if replication is not None:
+                line["replication"] = replication
+            if whole is not None:
+                line["whole_job"] = whole
+    elif rank == 0:
+        cnt = int(out[0][0])
+        got = (out[1][0, :cnt].astype(np.int64), out[2][0, :cnt].astype(np.int64))
+        value = args.steps * per_step / elapsed
         # HBM-side bytes per launch of the distance kernel come from a separate hardware-counter
         # run of this same workload (tools/collect_profiles.sh), kept beside the profiles.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "distance_kernel_traffic.json")
-        if os.path.exists(tpath) and args.pairs_per_step == 1:
+        if os.path.exists(tpath) and per_step == 1:
             with open(tpath) as fh:
                 traffic = json.load(fh).get(args.engine, {}).get("traffic_bytes_per_launch")
-        roof = roofline(st, args.engine, traffic)
         planted_found = len(set(zip(got[0].tolist(), got[1].tolist())) & set(map(tuple, truth.tolist())))
         line = {
             "metric": "image pairs/sec, 8k x 8k 128-d descriptors",
@@ -345,38 +570,57 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "single synthetic pair, 8192x8192 128-d float descriptors, "
                                    "ratio 0.8 + cross-check (BASELINE.json configs[1])",
-                       "engine": args.engine, "pairs_per_step_per_gpu": args.pairs_per_step, "planted_matches": PLANTED, "matches_found": cnt,
-                       "planted_found": planted_found, "parallelism": "pairs sharded over ranks, no collective"},
-            "frac_of_fp32_mfma_peak_end_to_end": value / world * flop_per_launch / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                       "engine": args.engine, "pairs_per_step_per_gpu": per_step, "planted_matches": PLANTED, "matches_found": cnt,
+                       "planted_found": planted_found, "parallelism": "one GPU"},
+            "frac_of_fp32_mfma_peak_end_to_end": value * flop_per_pair / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "rescanned_queries_per_pair": st["rescanned_queries"] / max(1, st["pairs"]),
             "upload_seconds_both_images": upload_s, "preheat_ms": args.preheat_ms,
             "pairs_per_s_this_gpu_without_kernel_timing": free_rate,
-            "roofline": roof,
+            "roofline": roofline(st, args.engine, traffic),
         }
-        if replication is not None:
-            line["replication"] = replication
-        if world == 1 and not args.no_other_engine:
+        if not args.no_other_engine:
             # the library's other distance engine on the same steps (its own timed region)
             other = "f16x3" if args.engine == "f32" else "f32"
-            o_out, o_elapsed, o_st = timed_region(other)
+            o_out, o_elapsed, o_st = timed_region(other, step, args.steps)
             o_cnt = int(o_out[0][0])
             same = (o_cnt == cnt and o_out[1][0, :cnt].tolist() == got[0].tolist()
                     and o_out[2][0, :cnt].tolist() == got[1].tolist())
-            o_value = args.steps * args.pairs_per_step / o_elapsed
+            o_value = args.steps * per_step / o_elapsed
             line["other_engine"] = {
                 "engine": other, "value": o_value, "unit": "pairs/s", "ms_per_step": o_elapsed / args.steps * 1e3,
-                "frac_of_fp32_mfma_peak_end_to_end": o_value * flop_per_launch / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                "frac_of_fp32_mfma_peak_end_to_end": o_value * flop_per_pair / (PEAK_FP32_MFMA_TFLOPS * 1e12),
                 "rescanned_queries_per_pair": o_st["rescanned_queries"] / max(1, o_st["pairs"]),
                 "matches_equal_main_engine": bool(same), "roofline": roofline(o_st, other, None)}
-        if world == 1 and not args.no_batched and args.pairs_per_step == 1:
+            m.set_engine(args.engine)
+        if not args.no_batched and per_step == 1:
             line["batched"] = batched_leg(m, args.engine)
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, B, got)
-        if world == 1 and not args.no_cascade:
+        if not args.no_whole_job:
+            try:
+                m.set_engine(args.engine)
+                job = SetJob(args.set_images or 100, 0, 1)
+                line["whole_job"] = whole_job_leg(m, job, barrier, max_over_ranks, device, args.engine)
+                cb = line.get("cpu_baseline")
+                if cb:
+                    # the reference cannot hold this job in memory (it queues deep copies for every task up
+                    # front); its cost is linear in pairs, so the one-pair timings are scaled, not measured
+                    n = line["whole_job"]["pairs"]
+                    line["whole_job"]["cpu_baseline"] = {
+                        "extrapolated": True, "kind": "port", "unit": "pairs/s",
+                        "sample": "one measured 8192x8192 pair x %d pairs (cost is linear in pairs)" % n,
+                        "value": cb["value"], "cores": cb["cores"], "seconds_whole_job": n * cb["seconds_per_pair"],
+                        "all_cores": {"value": cb["all_cores"]["value"], "cores": cb["all_cores"]["cores"],
+                                      "seconds_whole_job": n * cb["all_cores"]["seconds_per_pair"]}}
+                m.drop_all()
+            except Exception as e:   # an extra, never the reason the headline line is lost
+                line["whole_job"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_cascade:
             try:
                 line["cascade_hash"] = cascade_leg(m, not args.no_cpu_baseline)
             except Exception as e:   # an extra, never the reason the headline line is lost
                 line["cascade_hash"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if line is not None:
         print(json.dumps(line), flush=True)
 
     m.close()

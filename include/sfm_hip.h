@@ -151,6 +151,21 @@ int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t se
 #define SFM_HIP_ENGINE_F16X3 1
 int sfm_hip_set_engine(sfm_hip_ctx* ctx, int engine);
 
+/* Static partition of a pair list over the GPUs of a node (host-only: no GPU is touched).  The
+ * reference runs each pair as an independent task (brute_force_matcher.cc:46-61) over the
+ * lexicographic list of ExhaustivePairBuilder (exhaustive_pair_builder.cc:3-19); a multi-GPU caller
+ * gives shard s of this partition to GPU s and uploads to that GPU only the images its pairs name.
+ * pair_ids: 2*n_pairs image ids as in sfm_hip_match_pairs; image_ids / image_rows: every image the
+ * list names and its descriptor count (n_images entries, any order, ids distinct).  A pair costs
+ * rows(first) * rows(second); shards get equal cost to within one pair, and each shard is a compact
+ * 2-D block of the (first, second) triangle, so it names about 2 n / sqrt(n_shards) images, not n.
+ * out_order (n_pairs entries) receives the indices of the pairs, shard after shard; shard s owns
+ * out_order[out_shard_begin[s] .. out_shard_begin[s + 1]) (n_shards + 1 entries).  Inside a shard
+ * the pairs of one block keep the order of the list.  The result depends on the arguments only. */
+int sfm_hip_partition_pairs(const int64_t* pair_ids, int32_t n_pairs, const int64_t* image_ids,
+                            const int32_t* image_rows, int32_t n_images, int32_t n_shards,
+                            int32_t* out_order, int32_t* out_shard_begin);
+
 /* Wait for everything queued on the context (the reference's future.get(),
  * brute_force_matcher.cc:67-68,83). */
 int sfm_hip_sync(sfm_hip_ctx* ctx);

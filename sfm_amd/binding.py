@@ -15,7 +15,7 @@ EXPORTS = (
     "sfm_hip_upload_image", "sfm_hip_drop_image", "sfm_hip_drop_all_images", "sfm_hip_image_size",
     "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
     "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats", "sfm_hip_set_engine",
-    "sfm_hip_upload_image_device", "sfm_hip_match_pair_noalloc",
+    "sfm_hip_upload_image_device", "sfm_hip_match_pair_noalloc", "sfm_hip_partition_pairs",
     "sfm_hip_cascade_set_projection", "sfm_hip_cascade_column_sums", "sfm_hip_cascade_hash_images",
     "sfm_hip_cascade_get_hashes", "sfm_hip_cascade_match_pairs", "sfm_hip_cascade_reference_projection",
     "sfm_hip_cascade_image_order", "sfm_hip_cascade_prepare", "sfm_hip_cascade_get_stats",
@@ -76,6 +76,7 @@ def library():
     lib.sfm_hip_image_size.argtypes = [vp, i64, ctypes.POINTER(i32)]
     lib.sfm_hip_match_pairs.argtypes = [vp, vp, i32, ctypes.c_double, ctypes.c_int, vp, vp, vp, vp, i64]
     lib.sfm_hip_match_pair_noalloc.argtypes = [vp, i64, i64, ctypes.c_double, ctypes.c_int, vp, vp, vp, vp]
+    lib.sfm_hip_partition_pairs.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp]
     lib.sfm_hip_sync.argtypes = [vp]
     lib.sfm_hip_host_alloc.argtypes = [ctypes.c_size_t]
     lib.sfm_hip_host_alloc.restype = vp
@@ -98,6 +99,22 @@ def library():
     lib.sfm_hip_geometry_verify_pairs.argtypes = [vp, i32, vp, vp, vp, ctypes.c_uint64, i64, vp, vp, vp, vp]
     _lib = lib
     return lib
+
+
+def partition_pairs(pairs, image_rows, n_shards):
+    """sfm_hip_partition_pairs: (order, shard_begin).  pairs [n, 2] int64; image_rows {id: rows}.
+    Shard s owns the pairs order[shard_begin[s]:shard_begin[s + 1]] (indices into `pairs`)."""
+    p = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    ids = np.ascontiguousarray(sorted(int(i) for i in image_rows), dtype=np.int64)
+    rows = np.ascontiguousarray([int(image_rows[int(i)]) for i in ids], dtype=np.int32)
+    order = np.empty(max(len(p), 1), np.int32)
+    begin = np.empty(int(n_shards) + 1, np.int32)
+    rc = library().sfm_hip_partition_pairs(p.ctypes.data, len(p), ids.ctypes.data, rows.ctypes.data, len(ids),
+                                           int(n_shards), order.ctypes.data, begin.ctypes.data)
+    if rc != 0:
+        raise SfmHipError("sfm_hip_partition_pairs failed (%d): a pair names an image without a row count, "
+                          "an id appears twice, or a count is negative" % rc)
+    return order[:len(p)], begin
 
 
 def cascade_reference_projection():
@@ -208,13 +225,15 @@ class Matcher:
 
     def _outputs(self, n_pairs, stride):
         # Two sets, used in turn: the library overlaps consecutive calls, and two calls in
-        # flight must not write the same host buffers.
-        shape = (n_pairs, stride)
-        if self._bufs is None or self._bufs_shape != shape:
+        # flight must not write the same host buffers.  A set is kept while the stride stays
+        # and the pair count does not grow (a shorter call uses the leading rows), so arrays
+        # handed out earlier stay valid across a job's short last call.
+        if self._bufs is None or self._bufs_shape[1] != stride or self._bufs_shape[0] < n_pairs:
             if self._bufs:
                 self.sync()
                 for b in self._bufs:
                     b.free()
+            shape = (n_pairs, stride)
             self._bufs = [_Pinned(self._lib, s, t) for _ in range(2)
                           for s, t in (((n_pairs,), np.int32), (shape, np.int32), (shape, np.int32), (shape, np.float32))]
             self._bufs_shape = shape
@@ -231,7 +250,8 @@ class Matcher:
         self._check(self._lib.sfm_hip_match_pairs(self._h, p.ctypes.data, p.shape[0], float(ratio),
                                                   int(bool(cross_check)), cnt.ptr, lhs.ptr, rhs.ptr, dist.ptr,
                                                   int(stride)), "sfm_hip_match_pairs")
-        return cnt.array, lhs.array, rhs.array, dist.array
+        n = p.shape[0]
+        return cnt.array[:n], lhs.array[:n], rhs.array[:n], dist.array[:n]
 
     def sync(self):
         self._check(self._lib.sfm_hip_sync(self._h), "sfm_hip_sync")

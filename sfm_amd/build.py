@@ -49,6 +49,12 @@ def build_library(force=False):
         if force or _newer(obj, [src] + [os.path.join(CSRC, h) for h in headers] + shared):
             _run([HIPCC] + HIP_FLAGS + ["-c", "-o", obj, src])
         objs.append(obj)
+    for unit in ("sfm_hip_partition.cc",):   # host-only parts of the C ABI
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(LIBDIR, unit.replace(".cc", ".o"))
+        if force or _newer(obj, [src, shared[1]]):
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-c", "-o", obj, src])
+        objs.append(obj)
     if force or _newer(LIB, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

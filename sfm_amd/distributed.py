@@ -1,10 +1,13 @@
 """Static sharding of an image-pair list over the ranks of one node.
 
-Pairs are independent (each result depends on its two images only), so the data path
-needs no collective: every rank holds all descriptors, matches a contiguous slice of the
-lexicographically ordered pair list (the order of the reference's std::set<Pair>,
-src/feature_matcher/exhaustive_pair_builder.cc:11-16) and the per-pair match lists are
-gathered to rank 0.  The gather goes through torch.distributed (RCCL on GPUs, gloo on CPU).
+Pairs are independent (each result depends on its two images only; the reference runs them as
+separate tasks, src/feature_matcher/brute_force_matcher.cc:46-61), so the data path needs no
+collective.  The list -- in the order of the reference's std::set<Pair>,
+src/feature_matcher/exhaustive_pair_builder.cc:11-16 -- is partitioned by sfm_hip_partition_pairs
+(include/sfm_hip.h): every rank gets a compact 2-D block of the (first, second) triangle of equal
+cost, a pair costing rows(first) x rows(second), and needs only the images of its block.  The
+per-pair match lists are gathered to rank 0 as fixed-width int32 tensors through torch.distributed
+(RCCL on GPUs, gloo on CPU).
 """
 import numpy as np
 
@@ -21,53 +24,155 @@ def shard_bounds(n_items, rank, world):
 def exhaustive_pairs(image_ids):
     """All (min, max) pairs over the ids, lexicographic: what ExhaustivePairBuilder::BuildPair
     inserts into its std::set (src/feature_matcher/exhaustive_pair_builder.cc:3-19)."""
-    ids = sorted(int(i) for i in image_ids)
-    return np.array([(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]], dtype=np.int64).reshape(-1, 2)
+    ids = np.array(sorted(int(i) for i in image_ids), dtype=np.int64)
+    a, b = np.triu_indices(len(ids), k=1)
+    return np.stack([ids[a], ids[b]], axis=1).astype(np.int64).reshape(-1, 2)
 
 
-def match_pairs_sharded(matcher, pairs, ratio=0.8, cross_check=True, rank=0, world=1, group=None):
-    """Match this rank's slice with `matcher` (anything with match_pairs(pairs, ratio, cross_check))
-    and gather.  Returns the full, ordered list of (lhs, rhs, dist) on rank 0 and None elsewhere."""
+def partition(pairs, image_rows, world):
+    """[indices into `pairs` of rank r's shard, for r in range(world)], each in the order the rank
+    works through them.  image_rows: {image id: descriptor rows} for every image the list names, or
+    None when all images have the same size."""
+    from .binding import partition_pairs
     pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
-    lo, hi = shard_bounds(len(pairs), rank, world)
-    local = matcher.match_pairs(pairs[lo:hi], ratio, cross_check) if hi > lo else []
-    if world == 1:
-        return local
+    if image_rows is None:
+        image_rows = {int(i): 1 for i in np.unique(pairs)}
+    order, begin = partition_pairs(pairs, image_rows, world)
+    return [order[begin[r]:begin[r + 1]].astype(np.int64) for r in range(world)]
+
+
+def images_of(pairs, indices):
+    """Sorted ids of the images the pairs at `indices` name: what a rank has to upload."""
+    pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    return np.unique(pairs[np.asarray(indices, dtype=np.int64)]).tolist()
+
+
+def gather_flat(per_pair, columns, shards, rank, world, group=None, device=None, chunk_elems=1 << 24):
+    """Gather every rank's results to rank 0 as int32 tensors (no pickling).
+
+    per_pair: int32 [n_local, k] -- k numbers per pair of this rank's shard, in shard order; the LAST
+    one is the number of entries the pair owns in `columns`.  columns: list of c 4-byte arrays
+    (int32 / float32) of sum(per_pair[:, -1]) entries each, the pairs' entries one after the other.
+    shards: partition(...)'s result (every rank computes the same one).
+    Returns on rank 0 (per_pair_all int32 [n_pairs, k], offsets int64 [n_pairs + 1], columns_all) in
+    the order of the pair list, None elsewhere.  Payload travels in chunks of at most chunk_elems
+    entries per column, so rank 0 never holds more than world x c x chunk_elems x 4 bytes of staging.
+    """
+    import torch
     import torch.distributed as dist
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object((lo, local), gathered, dst=0, group=group)
+    per_pair = np.ascontiguousarray(per_pair, dtype=np.int32).reshape(len(shards[rank]), -1)
+    k, c = per_pair.shape[1], len(columns)
+    total = int(per_pair[:, -1].sum()) if len(per_pair) else 0
+    cols = np.empty((c, total), np.int32)
+    for j, col in enumerate(columns):
+        col = np.ascontiguousarray(col)
+        assert col.dtype.itemsize == 4 and col.size == total, "columns must be 4-byte arrays matching the counts"
+        cols[j] = col.view(np.int32)
+    dev = torch.device("cpu") if device is None else device
+    n_pairs = sum(len(x) for x in shards)
+    max_local = max(max(len(x) for x in shards), 1)
+
+    def gather(t):
+        t = t.to(dev)
+        parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, parts, dst=0, group=group)
+        return [x.cpu().numpy() for x in parts] if rank == 0 else None
+
+    padded = np.zeros((max_local, k), np.int32)
+    padded[:len(per_pair)] = per_pair
+    got = gather(torch.from_numpy(padded))
+    totals = torch.tensor([total], dtype=torch.int64, device=dev)
+    dist.all_reduce(totals, op=dist.ReduceOp.MAX, group=group)
+    max_total = int(totals.item())
+    per_rank = [np.empty((c, int(got[r][:len(shards[r]), -1].sum())), np.int32) for r in range(world)] if rank == 0 else None
+    for at in range(0, max_total, chunk_elems):
+        width = min(chunk_elems, max_total - at)
+        piece = np.zeros((c, width), np.int32)
+        mine = cols[:, at:at + width]
+        piece[:, :mine.shape[1]] = mine
+        parts = gather(torch.from_numpy(piece))
+        if rank == 0:
+            for r in range(world):
+                w = max(0, min(width, per_rank[r].shape[1] - at))
+                per_rank[r][:, at:at + w] = parts[r][:, :w]
     if rank != 0:
         return None
-    out = []
-    for lo_r, res in sorted(gathered, key=lambda t: t[0]):
-        assert lo_r == len(out), "shards do not tile the pair list"
-        out.extend(res)
-    return out
+    # back into list order
+    per_pair_all = np.zeros((n_pairs, k), np.int32)
+    for r in range(world):
+        per_pair_all[shards[r]] = got[r][:len(shards[r])]
+    offsets = np.zeros(n_pairs + 1, np.int64)
+    np.cumsum(per_pair_all[:, -1], out=offsets[1:])
+    columns_all = np.empty((c, int(offsets[-1])), np.int32)
+    for r in range(world):
+        cnt = got[r][:len(shards[r]), -1].astype(np.int64)
+        src = np.zeros(len(cnt) + 1, np.int64)
+        np.cumsum(cnt, out=src[1:])
+        dst = offsets[shards[r]]
+        # entry e of the rank's payload belongs to its pair q(e): moves by dst[q] - src[q]
+        shift = np.repeat(dst - src[:-1], cnt)
+        columns_all[:, np.arange(src[-1]) + shift] = per_rank[r]
+    return per_pair_all, offsets, [columns_all[j] for j in range(c)]
 
 
-def cascade_match_pairs_sharded(matcher, pairs, cross_check=True, rank=0, world=1, group=None):
+def _flatten(results, n_head):
+    """List of per-pair tuples (n_head leading ints, then equally long arrays) -> (per_pair, columns)."""
+    per_pair = np.array([[int(x) for x in t[:n_head]] + [len(t[n_head])] for t in results], np.int32).reshape(len(results), n_head + 1)
+    n_cols = 3
+    columns = []
+    for j in range(n_cols):
+        parts = [np.ascontiguousarray(t[n_head + j]) for t in results]
+        want = np.float32 if j == 2 else np.int32
+        columns.append(np.concatenate(parts).astype(want) if parts else np.zeros(0, want))
+    return per_pair, columns
+
+
+def match_pairs_sharded(matcher, pairs, ratio=0.8, cross_check=True, rank=0, world=1, group=None, image_rows=None,
+                        device=None):
+    """Match this rank's shard with `matcher` (anything with match_pairs(pairs, ratio, cross_check);
+    only the images of images_of(pairs, partition(...)[rank]) need to be uploaded to it) and gather.
+    Returns the full list of (lhs int32, rhs int32, dist float32) in the order of `pairs` on rank 0
+    and None elsewhere.  device: torch device the collective needs its tensors on (None: CPU, gloo)."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    shards = partition(pairs, image_rows, world)
+    mine = shards[rank]
+    local = matcher.match_pairs(pairs[mine], ratio, cross_check) if len(mine) else []
+    if world == 1:
+        out = [None] * len(pairs)
+        for q, res in zip(mine.tolist(), local):
+            out[q] = res
+        return out
+    per_pair, columns = _flatten(local, 0)
+    got = gather_flat(per_pair, columns, shards, rank, world, group, device)
+    if got is None:
+        return None
+    _, off, (lhs, rhs, dist_bits) = got
+    dist = dist_bits.view(np.float32)
+    return [(lhs[off[q]:off[q + 1]], rhs[off[q]:off[q + 1]], dist[off[q]:off[q + 1]]) for q in range(len(pairs))]
+
+
+def cascade_match_pairs_sharded(matcher, pairs, cross_check=True, rank=0, world=1, group=None, device=None):
     """The cascade-hash matcher over ranks.  Hashing depends on the mean vector of ALL images the
-    job's pair list names (cascade_hash_matcher.cc:148-165), so every rank prepares with the whole
-    list (matcher.cascade_prepare(pairs): every rank holds every image, as above) and only the
-    matching itself is sliced.  matcher: anything with cascade_prepare(pairs) and
+    job's pair list names (cascade_hash_matcher.cc:148-165), so every rank holds every image and
+    prepares with the whole list (matcher.cascade_prepare(pairs)); only the matching itself is
+    shared out, in contiguous slices of the list.  matcher: anything with cascade_prepare(pairs) and
     cascade_match_pairs(pairs, cross_check).  Returns the full, ordered list of
     (n_default, lhs, rhs, dist) on rank 0 and None elsewhere."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
     matcher.cascade_prepare(pairs)
-    lo, hi = shard_bounds(len(pairs), rank, world)
-    local = matcher.cascade_match_pairs(pairs[lo:hi], cross_check) if hi > lo else []
+    shards = [np.arange(*shard_bounds(len(pairs), r, world), dtype=np.int64) for r in range(world)]
+    mine = shards[rank]
+    local = matcher.cascade_match_pairs(pairs[mine], cross_check) if len(mine) else []
     if world == 1:
         return local
-    import torch.distributed as dist
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object((lo, local), gathered, dst=0, group=group)
-    if rank != 0:
+    per_pair, columns = _flatten(local, 1)
+    got = gather_flat(per_pair, columns, shards, rank, world, group, device)
+    if got is None:
         return None
-    out = []
-    for lo_r, res in sorted(gathered, key=lambda t: t[0]):
-        assert lo_r == len(out), "shards do not tile the pair list"
-        out.extend(res)
-    return out
+    head, off, (lhs, rhs, dist_bits) = got
+    dist = dist_bits.view(np.float32)
+    return [(int(head[q, 0]), lhs[off[q]:off[q + 1]], rhs[off[q]:off[q + 1]], dist[off[q]:off[q + 1]])
+            for q in range(len(pairs))]
 
 
 def replicate_images(matcher, images, rank=0, world=1, group=None, device=None, method="collective"):

@@ -58,11 +58,13 @@ void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int
   }
 }
 
-// One GPU: upload the images its pairs touch, then match its slice of the pair list in batches.
+// One GPU: upload the images its pairs touch, then match its shard of the pair list (indices into
+// jobs) in batches.
 // Two sets of pinned result buffers alternate, so the GPU works on batch b while this thread
 // turns batch b-1 into Match records.
-void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t hi, double ratio, bool cross,
+void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<size_t>& shard, double ratio, bool cross,
                 int engine, Progress& progress, int helpers) {
+  if (shard.empty()) return;
   sfm_hip_ctx* ctx = nullptr;
   if (sfm_hip_ctx_create(device, &ctx) != SFM_HIP_OK) fail(nullptr, "sfm_hip_ctx_create");
   struct Guard {
@@ -80,8 +82,7 @@ void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t 
   // pairs of the list's first image need every other image at once, whereas in this order the k-th
   // new image brings k - 1 new pairs, so from a handful of images on the GPU has more to do than
   // the uploads take.  (Where a pair's result lands does not depend on when it is computed.)
-  std::vector<size_t> order(hi - lo);
-  for (size_t k = 0; k < order.size(); k++) order[k] = lo + k;
+  std::vector<size_t> order(shard);
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
     const IndexT ma = std::max(jobs[a].pair.first, jobs[a].pair.second);
     const IndexT mb = std::max(jobs[b].pair.first, jobs[b].pair.second);
@@ -91,7 +92,7 @@ void run_device(int device, const std::vector<PairJob>& jobs, size_t lo, size_t 
   // busy with the batch before.
   std::set<IndexT> uploaded;
   int64_t stride = 1;
-  for (size_t p = lo; p < hi; p++) stride = std::max<int64_t>(stride, (int64_t)jobs[p].first->size());
+  for (size_t p : shard) stride = std::max<int64_t>(stride, (int64_t)jobs[p].first->size());
   auto upload_for = [&](size_t b0, size_t b1) {     // positions in 'order'
     for (size_t q = b0; q < b1; q++) {
       const size_t p = order[q];
@@ -230,24 +231,47 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
   // host threads that turn index lists into Match records, per GPU
   const unsigned cores = std::thread::hardware_concurrency();
   const int helpers = (int)std::max(1u, std::min(8u, (cores ? cores : 8u) / (unsigned)n_dev));
-  // static contiguous shards, sizes differ by at most one
+  // Static shards: compact 2-D blocks of the (first, second) triangle of equal cost, where a pair
+  // costs rows(first) x rows(second) (sfm_hip_partition_pairs); a GPU uploads only its block's images.
+  std::vector<std::vector<size_t>> shards((size_t)n_dev);
+  {
+    std::vector<int64_t> flat(2 * jobs.size()), ids;
+    std::vector<int32_t> rows;
+    for (size_t k = 0; k < jobs.size(); k++) {
+      flat[2 * k] = jobs[k].pair.first;
+      flat[2 * k + 1] = jobs[k].pair.second;
+    }
+    std::set<IndexT> named;
+    for (const PairJob& j : jobs) {
+      if (named.insert(j.pair.first).second) {
+        ids.push_back(j.pair.first);
+        rows.push_back((int32_t)j.first->size());
+      }
+      if (named.insert(j.pair.second).second) {
+        ids.push_back(j.pair.second);
+        rows.push_back((int32_t)j.second->size());
+      }
+    }
+    std::vector<int32_t> order(jobs.size()), begin((size_t)n_dev + 1);
+    if (sfm_hip_partition_pairs(flat.data(), (int32_t)jobs.size(), ids.data(), rows.data(), (int32_t)ids.size(), n_dev,
+                                order.data(), begin.data()) != SFM_HIP_OK)
+      throw std::runtime_error("HipBruteForceMatcher: sfm_hip_partition_pairs refused the pair list");
+    for (int d = 0; d < n_dev; d++)
+      shards[(size_t)d].assign(order.begin() + begin[(size_t)d], order.begin() + begin[(size_t)d + 1]);
+  }
   Progress progress;
   progress.total = (int)jobs.size();
   progress.print = print_progress_;
   std::vector<std::thread> workers;
   std::vector<std::exception_ptr> errors((size_t)n_dev);
-  const size_t base = jobs.size() / n_dev, extra = jobs.size() % n_dev;
-  size_t lo = 0;
   for (int d = 0; d < n_dev; d++) {
-    const size_t hi = lo + base + ((size_t)d < extra ? 1 : 0);
-    workers.emplace_back([&, d, lo, hi] {
+    workers.emplace_back([&, d] {
       try {
-        run_device(d % visible, jobs, lo, hi, ratio_, is_cross_valid, engine, progress, helpers);
+        run_device(d % visible, jobs, shards[(size_t)d], ratio_, is_cross_valid, engine, progress, helpers);
       } catch (...) {
         errors[(size_t)d] = std::current_exception();
       }
     });
-    lo = hi;
   }
   for (auto& t : workers) t.join();
   for (auto& e : errors)

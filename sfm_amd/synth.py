@@ -99,6 +99,31 @@ def make_image_set(n_images, n_features, shared_fraction, seed, sigma=0.01):
     return out
 
 
+def scene_pool(planted, seed):
+    """The rows every image of a scene set shares (see scene_image)."""
+    return rootsift_rows(planted, _stream(seed, 12))
+
+
+def scene_positions(img, n_features, planted, seed):
+    """Row of image `img` that holds pool row r, for r < planted (needs no descriptor data)."""
+    return permutation(n_features, _stream(_stream(seed, 200 + img), 3))[:planted]
+
+
+def scene_image(img, n_features, pool, seed, sigma=0.01):
+    """Image `img` of a scene set: a noisy copy of EVERY pool row at the rows scene_positions()
+    names, independent rows elsewhere.  Any two images of the set therefore share exactly
+    len(pool) true correspondences: row scene_positions(a)[r] of image a with row
+    scene_positions(b)[r] of image b.  An image depends on (img, seed) only, so every process
+    generates the images it needs and no others."""
+    s = _stream(seed, 200 + img)
+    X = rootsift_rows(n_features, _stream(s, 1))
+    k = len(pool)
+    if k:
+        dst = scene_positions(img, n_features, k, seed)
+        X[dst] = (pool.astype(np.float64) + noise(k, _stream(s, 4), sigma)).astype(np.float32)
+    return X
+
+
 def make_repetitive_set(n_images, n_features, shared_fraction, copies, seed, sigma=0.002):
     """Like make_image_set, but every shared scene row appears `copies` times in an image, each
     time with its own small noise (repeated structure, as the windows of a facade produce).  A

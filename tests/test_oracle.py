@@ -57,6 +57,19 @@ def test_oracle_reproduces_committed_fixtures(case):
     assert got == case
 
 
+def _golden_sets():
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_cases.json")) as f:
+        return json.load(f)["set_cases"]
+
+
+@pytest.mark.parametrize("case", _golden_sets(), ids=lambda c: c["name"])
+def test_oracle_reproduces_committed_set_fixtures(case):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    assert make_golden.run_set_case((case["name"], case["n_images"], case["n_features"], case["seed"])) == case
+
+
 def test_threaded_oracle_equals_serial():
     A, B, _ = synth.make_pair(300, 260, 120, seed=8)
     for cross in (True, False):
