@@ -148,7 +148,7 @@ def cascade_leg(m, with_cpu, n_images=32, reps=40):
     return leg
 
 
-def replication_check(m, rank, world, local_rank, barrier, n_images=64):
+def replication_check(m, rank, world, device, barrier, n_images=64):
     """Outside the timed region, N > 1 only: how long it takes to give every GPU a descriptor set
     of n_images x 8192 rows (i) by uploading everything from each rank's host memory and (ii) by
     uploading each rank's share and all-gathering over RCCL/xGMI.  Reported, never fatal."""
@@ -165,9 +165,9 @@ def replication_check(m, rank, world, local_rank, barrier, n_images=64):
         for name, method, src in (("host_uploads_s", "host", images), ("collective_s", "collective", mine)):
             barrier()
             t0 = time.perf_counter()
-            replicate_images(m, src, rank, world, device=torch.device("cuda", local_rank), method=method)
+            replicate_images(m, src, rank, world, device=device if device.type == "cuda" else None, method=method)
             barrier()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             out[name] = float(tt.item())
             for i in ids:
@@ -403,8 +403,15 @@ def main():
     # SFM_BENCH_FORCE_DIST=1 takes the multi-rank code path (sharded job, RCCL group, barriers, max
     # over ranks, gather) even with one rank: a rehearsal for machines with a single GPU
     dist_on = world > 1 or os.environ.get("SFM_BENCH_FORCE_DIST") == "1"
+    # SFM_BENCH_BACKEND=gloo: collectives over CPU tensors, ranks share the visible GPUs round robin --
+    # lets several ranks rehearse the multi-rank path on a machine with one GPU (RCCL refuses two
+    # ranks on one device).  The default, nccl, is RCCL: one rank per GPU.
+    backend = os.environ.get("SFM_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank if dist_on else 0)
     device = torch.device("cuda", local_rank if dist_on else 0)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
 
     import sfm_amd
     from sfm_amd import synth
@@ -447,7 +454,10 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     def barrier():
         if dist_on:
@@ -457,7 +467,7 @@ def main():
     def max_over_ranks(x):
         if not dist_on:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=device)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -516,11 +526,11 @@ def main():
             m.match_pairs_async(one, 0.8, True, stride=N_FEATURES)
         m.sync()
         rate = args.steps / (time.perf_counter() - t1)
-        rates = torch.zeros(world, dtype=torch.float64, device=device)
+        rates = torch.zeros(world, dtype=torch.float64, device=coll_device)
         rates[rank] = rate
         dist.all_reduce(rates)
-        replication = None if args.no_replication_check else replication_check(m, rank, world, local_rank, barrier)
-        whole = None if args.no_whole_job else whole_job_leg(m, job, barrier, max_over_ranks, device, args.engine)
+        replication = None if args.no_replication_check else replication_check(m, rank, world, coll_device, barrier)
+        whole = None if args.no_whole_job else whole_job_leg(m, job, barrier, max_over_ranks, coll_device, args.engine)
         if rank == 0:
             value = args.steps * per_step * world / elapsed
             cnt = out[0]

@@ -79,6 +79,29 @@ int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descri
  * written while the call runs; it is not needed afterwards.  Blocking. */
 int sfm_hip_upload_image_device(sfm_hip_ctx* ctx, int64_t image_id, const float* device_descriptors, int32_t n);
 
+/* Give every one of n_ctx contexts (one per GPU, all driven by this process) every one of n_images
+ * images: image_ids[i] has rows[i] descriptors at descriptors[i] (host memory, the layout of
+ * sfm_hip_upload_image).  The images are cut into n_ctx shares of about equal size; each context's
+ * GPU receives only its share from the host (so an image crosses PCIe once, and all n_ctx links
+ * work at the same time), then ONE all-gather over RCCL/xGMI hands every share to every GPU, and
+ * every context registers all images as sfm_hip_upload_image_device does.  The alternative --
+ * sfm_hip_upload_image of every image on every context -- moves n_ctx times the bytes over PCIe;
+ * which is faster depends on the machine (out_times, if not NULL, receives where the time went).
+ * Afterwards the contexts are as after n_ctx * n_images calls of sfm_hip_upload_image.
+ * No counterpart in the reference, whose images only live in host memory
+ * (brute_force_matcher.cc:47-52 copies them per task).  RCCL is loaded when this is first called;
+ * without a loadable librccl the call fails with SFM_HIP_ERR_HIP and the contexts are unchanged.
+ * Contexts must sit on distinct devices.  Blocking; at most one call at a time per process. */
+typedef struct {
+  double comm_init_s;   /* creating the communicators (first call for a set of devices only) */
+  double upload_s;      /* host -> device, each GPU its own share */
+  double allgather_s;   /* the collective */
+  double register_s;    /* padding, norms and split planes of every image on every GPU */
+} sfm_hip_replicate_times;
+int sfm_hip_replicate_images(sfm_hip_ctx* const* ctxs, int32_t n_ctx, const int64_t* image_ids,
+                             const float* const* descriptors, const int32_t* rows, int32_t n_images,
+                             sfm_hip_replicate_times* out_times);
+
 /* Forget one image / all images and free their device memory. */
 int sfm_hip_drop_image(sfm_hip_ctx* ctx, int64_t image_id);
 int sfm_hip_drop_all_images(sfm_hip_ctx* ctx);

@@ -16,6 +16,7 @@ EXPORTS = (
     "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
     "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats", "sfm_hip_set_engine",
     "sfm_hip_upload_image_device", "sfm_hip_match_pair_noalloc", "sfm_hip_partition_pairs",
+    "sfm_hip_replicate_images",
     "sfm_hip_cascade_set_projection", "sfm_hip_cascade_column_sums", "sfm_hip_cascade_hash_images",
     "sfm_hip_cascade_get_hashes", "sfm_hip_cascade_match_pairs", "sfm_hip_cascade_reference_projection",
     "sfm_hip_cascade_image_order", "sfm_hip_cascade_prepare", "sfm_hip_cascade_get_stats",
@@ -33,6 +34,11 @@ class Stats(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_uint64), ("queries", ctypes.c_uint64), ("rescanned_queries", ctypes.c_uint64),
                 ("distance_launches", ctypes.c_uint64), ("distance_ms", ctypes.c_double),
                 ("distance_flop", ctypes.c_double)]
+
+
+class ReplicateTimes(ctypes.Structure):
+    _fields_ = [("comm_init_s", ctypes.c_double), ("upload_s", ctypes.c_double), ("allgather_s", ctypes.c_double),
+                ("register_s", ctypes.c_double)]
 
 
 class CascadeStats(ctypes.Structure):
@@ -77,6 +83,7 @@ def library():
     lib.sfm_hip_match_pairs.argtypes = [vp, vp, i32, ctypes.c_double, ctypes.c_int, vp, vp, vp, vp, i64]
     lib.sfm_hip_match_pair_noalloc.argtypes = [vp, i64, i64, ctypes.c_double, ctypes.c_int, vp, vp, vp, vp]
     lib.sfm_hip_partition_pairs.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp]
+    lib.sfm_hip_replicate_images.argtypes = [vp, i32, vp, vp, vp, i32, ctypes.POINTER(ReplicateTimes)]
     lib.sfm_hip_sync.argtypes = [vp]
     lib.sfm_hip_host_alloc.argtypes = [ctypes.c_size_t]
     lib.sfm_hip_host_alloc.restype = vp
@@ -115,6 +122,25 @@ def partition_pairs(pairs, image_rows, n_shards):
         raise SfmHipError("sfm_hip_partition_pairs failed (%d): a pair names an image without a row count, "
                           "an id appears twice, or a count is negative" % rc)
     return order[:len(p)], begin
+
+
+def replicate_images(matchers, images):
+    """sfm_hip_replicate_images: every Matcher of the list (one per GPU, this process) gets every
+    image of {id: float32 [n, 128]}; each image crosses PCIe once, the rest is one RCCL all-gather.
+    Returns where the time went."""
+    ids = sorted(int(i) for i in images)
+    arrays = [np.ascontiguousarray(images[i], dtype=np.float32).reshape(-1, 128) for i in ids]
+    id_arr = np.ascontiguousarray(ids, dtype=np.int64)
+    rows = np.ascontiguousarray([len(a) for a in arrays], dtype=np.int32)
+    ptrs = (ctypes.c_void_p * max(len(ids), 1))(*[a.ctypes.data for a in arrays])
+    handles = (ctypes.c_void_p * len(matchers))(*[m._h.value for m in matchers])
+    times = ReplicateTimes()
+    rc = library().sfm_hip_replicate_images(handles, len(matchers), id_arr.ctypes.data, ptrs, rows.ctypes.data, len(ids),
+                                            ctypes.byref(times))
+    if rc != 0:
+        raise SfmHipError("sfm_hip_replicate_images failed (%d): %s"
+                          % (rc, library().sfm_hip_last_error(matchers[0]._h).decode()))
+    return {f: getattr(times, f) for f, _ in ReplicateTimes._fields_}
 
 
 def cascade_reference_projection():

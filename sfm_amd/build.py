@@ -41,7 +41,7 @@ def build_library(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     shared = [os.path.join(CSRC, "ctx.hpp"), os.path.join(ROOT, "include", "sfm_hip.h")]
     units = {"sfm_hip_capi.hip": ["bf_kernels.hpp"], "sfm_hip_cascade.hip": ["cascade_kernels.hpp"],
-             "sfm_hip_geometry.hip": ["geometry_kernels.hpp"]}
+             "sfm_hip_geometry.hip": ["geometry_kernels.hpp"], "sfm_hip_replicate.hip": []}
     objs = []
     for unit, headers in units.items():
         src = os.path.join(CSRC, unit)
@@ -56,7 +56,7 @@ def build_library(force=False):
             _run(["g++", "-O2", "-std=c++17", "-fPIC", "-c", "-o", obj, src])
         objs.append(obj)
     if force or _newer(LIB, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -109,9 +109,9 @@ def gather_flat(per_pair, columns, shards, rank, world, group=None, device=None,
         src = np.zeros(len(cnt) + 1, np.int64)
         np.cumsum(cnt, out=src[1:])
         dst = offsets[shards[r]]
-        # entry e of the rank's payload belongs to its pair q(e): moves by dst[q] - src[q]
-        shift = np.repeat(dst - src[:-1], cnt)
-        columns_all[:, np.arange(src[-1]) + shift] = per_rank[r]
+        # pair by pair: a shard is a 2-D block of the triangle, so its pairs lie scattered over the list
+        for q in range(len(cnt)):
+            columns_all[:, dst[q]:dst[q] + cnt[q]] = per_rank[r][:, src[q]:src[q + 1]]
     return per_pair_all, offsets, [columns_all[j] for j in range(c)]
 
 

@@ -63,10 +63,14 @@ void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int
 // Two sets of pinned result buffers alternate, so the GPU works on batch b while this thread
 // turns batch b-1 into Match records.
 void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<size_t>& shard, double ratio, bool cross,
-                int engine, Progress& progress, int helpers) {
-  if (shard.empty()) return;
-  sfm_hip_ctx* ctx = nullptr;
-  if (sfm_hip_ctx_create(device, &ctx) != SFM_HIP_OK) fail(nullptr, "sfm_hip_ctx_create");
+                int engine, Progress& progress, int helpers, sfm_hip_ctx* resident_ctx) {
+  // resident_ctx: a context that already holds every image (replication by collective); this worker
+  // takes it over.  Otherwise the worker makes its own and uploads what its shard names.
+  sfm_hip_ctx* ctx = resident_ctx;
+  if (!ctx) {
+    if (shard.empty()) return;
+    if (sfm_hip_ctx_create(device, &ctx) != SFM_HIP_OK) fail(nullptr, "sfm_hip_ctx_create");
+  }
   struct Guard {
     sfm_hip_ctx* c;
     std::vector<void*> pinned;
@@ -76,6 +80,7 @@ void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<
       sfm_hip_ctx_destroy(c);
     }
   } guard{ctx, {}};
+  if (shard.empty()) return;
   if (engine >= 0 && sfm_hip_set_engine(ctx, engine) != SFM_HIP_OK) fail(ctx, "sfm_hip_set_engine");
 
   // Work through the shard in the order of each pair's larger image id, not in list order: the
@@ -94,6 +99,7 @@ void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<
   int64_t stride = 1;
   for (size_t p : shard) stride = std::max<int64_t>(stride, (int64_t)jobs[p].first->size());
   auto upload_for = [&](size_t b0, size_t b1) {     // positions in 'order'
+    if (resident_ctx) return;
     for (size_t q = b0; q < b1; q++) {
       const size_t p = order[q];
       const IndexT ids[2] = {jobs[p].pair.first, jobs[p].pair.second};
@@ -259,6 +265,50 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
     for (int d = 0; d < n_dev; d++)
       shards[(size_t)d].assign(order.begin() + begin[(size_t)d], order.begin() + begin[(size_t)d + 1]);
   }
+  // Replication by collective: contexts are made here, every image goes to one GPU over PCIe and to
+  // the others in one RCCL all-gather, and the workers start with everything resident.
+  int replication = replication_;
+  if (replication < 0) {
+    replication = 0;
+    if (const char* env = std::getenv("SFM_HIP_REPLICATION")) {
+      const std::string name(env);
+      if (name == "collective") replication = 1;
+      else if (name != "host")
+        throw std::runtime_error("HipBruteForceMatcher: SFM_HIP_REPLICATION must be host or collective, got '" + name + "'");
+    }
+  }
+  std::vector<sfm_hip_ctx*> resident((size_t)n_dev, nullptr);
+  if (replication == 1) {
+    if (n_dev > visible) throw std::runtime_error("HipBruteForceMatcher: replication by collective needs one GPU per shard");
+    auto destroy_all = [&] {
+      for (sfm_hip_ctx* c : resident) sfm_hip_ctx_destroy(c);
+    };
+    for (int d = 0; d < n_dev; d++)
+      if (sfm_hip_ctx_create(d, &resident[(size_t)d]) != SFM_HIP_OK) {
+        destroy_all();
+        fail(nullptr, "sfm_hip_ctx_create");
+      }
+    std::vector<int64_t> ids;
+    std::vector<const float*> data;
+    std::vector<int32_t> rows;
+    std::set<IndexT> named;
+    for (const PairJob& j : jobs) {
+      const IndexT two[2] = {j.pair.first, j.pair.second};
+      const Descriptors* ds[2] = {j.first, j.second};
+      for (int k = 0; k < 2; k++)
+        if (named.insert(two[k]).second) {
+          ids.push_back(two[k]);
+          data.push_back(ds[k]->data());
+          rows.push_back((int32_t)ds[k]->size());
+        }
+    }
+    if (sfm_hip_replicate_images(resident.data(), n_dev, ids.data(), data.data(), rows.data(), (int32_t)ids.size(), nullptr) !=
+        SFM_HIP_OK) {
+      const std::string msg = std::string("HipBruteForceMatcher: sfm_hip_replicate_images: ") + sfm_hip_last_error(resident[0]);
+      destroy_all();
+      throw std::runtime_error(msg);
+    }
+  }
   Progress progress;
   progress.total = (int)jobs.size();
   progress.print = print_progress_;
@@ -267,7 +317,8 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
   for (int d = 0; d < n_dev; d++) {
     workers.emplace_back([&, d] {
       try {
-        run_device(d % visible, jobs, shards[(size_t)d], ratio_, is_cross_valid, engine, progress, helpers);
+        run_device(d % visible, jobs, shards[(size_t)d], ratio_, is_cross_valid, engine, progress, helpers,
+                   resident[(size_t)d]);
       } catch (...) {
         errors[(size_t)d] = std::current_exception();
       }

@@ -12,6 +12,10 @@
 //     reference's two worker threads.
 // The distance engine (include/sfm_hip.h: SFM_HIP_ENGINE_F32 / SFM_HIP_ENGINE_F16X3) can be chosen
 // with set_engine() or the environment variable SFM_HIP_ENGINE=f32|f16x3; the matches are the same.
+// How the descriptors reach the GPUs can be chosen with set_replication() or SFM_HIP_REPLICATION:
+// "host" (default) -- every GPU uploads, from host memory, the images its shard of the pair list
+// names; "collective" -- every image is uploaded to one GPU only and an RCCL all-gather over xGMI
+// hands everything to all GPUs (sfm_hip_replicate_images).
 #ifndef SFM_AMD_HOST_HIP_BRUTE_FORCE_MATCHER_HPP_
 #define SFM_AMD_HOST_HIP_BRUTE_FORCE_MATCHER_HPP_
 #include "feature_matcher_interface.hpp"
@@ -25,12 +29,15 @@ class HipBruteForceMatcher : public FeatureMatcherInterface {
   ~HipBruteForceMatcher() override = default;
   // engine < 0: use SFM_HIP_ENGINE if set, else the library's default.
   void set_engine(int engine) { engine_ = engine; }
+  // 0: host uploads, 1: collective; < 0: use SFM_HIP_REPLICATION if set, else host uploads.
+  void set_replication(int mode) { replication_ = mode; }
 
  private:
   int n_devices_;
   double ratio_;        // the reference hard-codes 0.8 (brute_force_matcher.cc:35)
   bool print_progress_;
   int engine_ = -1;
+  int replication_ = -1;
 };
 
 // When this file is compiled into the reference tree in place of brute_force_matcher.cc,

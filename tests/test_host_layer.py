@@ -153,14 +153,17 @@ def test_gpu_stage_driver(tmp_path, cross):
 
 
 @pytest.mark.gpu
-def test_gpu_stage_driver_many_images(tmp_path):
+@pytest.mark.parametrize("replication", ["host", "collective"])
+def test_gpu_stage_driver_many_images(tmp_path, replication):
+    """Both ways of getting the descriptors onto the GPU(s): uploads from the host, or every image to
+    one GPU and an RCCL all-gather (SFM_HIP_REPLICATION, sfm_hip_replicate_images)."""
     exe = os.path.join(ROOT, "sfm_amd", "lib", "feature_match_main")
     imgs = synth.make_image_set(5, 400, 0.5, seed=77)
     images = {10 * i + 1: im[:n] for i, (im, n) in enumerate(zip(imgs, (400, 250, 129, 400, 1)))}
     kps = {i: synth.keypoints(len(d), i) for i, d in images.items()}
     path = str(tmp_path / "sfm_data.bin")
     write_sfm_bin(path, images, kps)
-    subprocess.run([exe, path], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([exe, path], check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, SFM_HIP_REPLICATION=replication))
     data = read_sfm_bin(path)
     ids = sorted(images)
     assert sorted(data["matches"]) == [(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]]

@@ -47,3 +47,25 @@ def test_images_registered_from_device_memory(matcher):
     assert [matcher.image_size(i) for i in (200, 201, 202)] == [900, 411, 0]
     for (a, b), got in zip([(200, 201), (201, 202)], matcher.match_pairs([(200, 201), (201, 202)], 0.8, True)):
         assert_same(got, oracle.match_pair(images[a], images[b], 0.8, True, threads=4))
+
+
+def test_replicate_images_entry_point_one_context(matcher):
+    """sfm_hip_replicate_images (one process, RCCL loaded at run time) on the one GPU of the box: a
+    communicator of one rank, an in-place all-gather, every image registered from device memory."""
+    from sfm_amd.binding import replicate_images
+    imgs = synth.make_image_set(4, 700, 0.6, seed=62)
+    images = {410: imgs[0], 405: imgs[1][:333], 407: imgs[2][:0], 401: imgs[3][:1]}
+    times = replicate_images([matcher], images)
+    assert set(times) == {"comm_init_s", "upload_s", "allgather_s", "register_s"} and all(v >= 0 for v in times.values())
+    assert [matcher.image_size(i) for i in (401, 405, 407, 410)] == [1, 333, 0, 700]
+    pairs = [(401, 405), (405, 410), (407, 410), (405, 407), (401, 410)]
+    for (a, b), got in zip(pairs, matcher.match_pairs(pairs, 0.8, True)):
+        assert_same(got, oracle.match_pair(images[a], images[b], 0.8, True, threads=4))
+    # a second call replaces the images (same communicator), a duplicated id is refused
+    images[405] = imgs[1][:500]
+    replicate_images([matcher], images)
+    assert matcher.image_size(405) == 500
+    assert_same(matcher.match_pairs([(405, 410)], 0.8, True)[0], oracle.match_pair(images[405], images[410], 0.8, True, threads=4))
+    import sfm_amd
+    with pytest.raises(sfm_amd.SfmHipError, match="one GPU per context"):
+        replicate_images([matcher, matcher], images)
