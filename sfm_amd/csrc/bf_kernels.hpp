@@ -1428,7 +1428,12 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
 #pragma unroll
     for (int c = 0; c < NCAND; c++) {
       const uint32_t ci = cand[tid * NCAND + c];
-      if (ci != SENT) {
+      // A column list may hold one row under two keys (its third key can repeat the second), so two
+      // candidates can name the same descriptor: it is one descriptor and enters the top-2 once.
+      bool seen = false;
+#pragma unroll
+      for (int e = 0; e < c; e++) seen = seen || cand[tid * NCAND + e] == ci;
+      if (ci != SENT && !seen) {
         const float rsq = res_r[tid * NCAND + c];
         top2_add(t, sqrtf(rsq), rsq, (int32_t)ci);
       }

@@ -72,8 +72,9 @@ struct Lane {
   bool tail_pending = false;            // tail_done was recorded and not waited for yet
   // host memory the lane's latest tail writes (counts, lhs, rhs, distances): a later batch on another
   // lane that writes any of it again waits for this tail, so that results land in call order
-  const char* out_lo[4] = {nullptr, nullptr, nullptr, nullptr};
-  const char* out_hi[4] = {nullptr, nullptr, nullptr, nullptr};
+  // (the cascade-hash path has a fifth array, the default-record counts)
+  const char* out_lo[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const char* out_hi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool half_queued = false;             // a distance kernel was queued and the call failed before its tail was
 };
 
@@ -196,6 +197,28 @@ inline void free_image(Image& im) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// A caller may hand the same output memory to consecutive calls (two sets of buffers used in turn,
+// say).  Batches of different lanes run on different streams and are not ordered among themselves,
+// so before lane L's batch writes the ranges [lo[a], hi[a]) its stream waits for every pending
+// batch of another lane that writes memory overlapping them; then the ranges become L's.
+inline int order_outputs(sfm_hip_ctx* ctx, Lane& L, hipStream_t st, const char* const (&lo)[5], const char* const (&hi)[5]) {
+  for (Lane& other : ctx->lanes) {
+    if (&other == &L || !other.tail_pending) continue;
+    bool overlap = false;
+    for (int a = 0; a < 5 && !overlap; a++)
+      for (int b = 0; b < 5 && !overlap; b++)
+        overlap = lo[a] && other.out_lo[b] && lo[a] < other.out_hi[b] && other.out_lo[b] < hi[a];
+#ifndef SFM_ABLATE_OUTPUT_ORDER   // diagnostic build: shows that the test of this ordering can fail
+    if (overlap) HIP_TRY(ctx, hipStreamWaitEvent(st, other.tail_done, 0));
+#endif
+  }
+  for (int a = 0; a < 5; a++) {
+    L.out_lo[a] = lo[a];
+    L.out_hi[a] = hi[a];
+  }
+  return SFM_HIP_OK;
+}
 
 // Device address through which a kernel can write a host output buffer
 // directly, or nullptr when the buffer is ordinary pageable memory.

@@ -581,28 +581,13 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       // no distance kernel to wait for, but the tail reads the tables
       HIP_TRY(ctx, hipStreamWaitEvent(st, L.stage_free[slot], 0));
     }
-    // A caller may hand the same output memory to consecutive calls (two sets of buffers used in
-    // turn, say).  Tails of different lanes are not ordered among themselves, so this tail waits
-    // for every pending tail that writes memory this one writes too.
+    // Results land in call order even when calls share output memory (order_outputs, ctx.hpp).
     {
-      const char* lo[4] = {(const char*)(out_counts + done), (const char*)(out_lhs_idx + o), (const char*)(out_rhs_idx + o),
-                           out_dist ? (const char*)(out_dist + o) : nullptr};
-      const char* hi[4] = {lo[0] + (size_t)count * 4, lo[1] + out_words * 4, lo[2] + out_words * 4,
-                           lo[3] ? lo[3] + out_words * 4 : nullptr};
-      for (Lane& other : ctx->lanes) {
-        if (&other == &L || !other.tail_pending) continue;
-        bool overlap = false;
-        for (int a = 0; a < 4 && !overlap; a++)
-          for (int b = 0; b < 4 && !overlap; b++)
-            overlap = lo[a] && other.out_lo[b] && lo[a] < other.out_hi[b] && other.out_lo[b] < hi[a];
-#ifndef SFM_ABLATE_OUTPUT_ORDER   // diagnostic build: shows that the test of this ordering can fail
-        if (overlap) HIP_TRY(ctx, hipStreamWaitEvent(st, other.tail_done, 0));
-#endif
-      }
-      for (int a = 0; a < 4; a++) {
-        L.out_lo[a] = lo[a];
-        L.out_hi[a] = hi[a];
-      }
+      const char* const lo[5] = {(const char*)(out_counts + done), (const char*)(out_lhs_idx + o), (const char*)(out_rhs_idx + o),
+                                 out_dist ? (const char*)(out_dist + o) : nullptr, nullptr};
+      const char* const hi[5] = {lo[0] + (size_t)count * 4, lo[1] + out_words * 4, lo[2] + out_words * 4,
+                                 lo[3] ? lo[3] + out_words * 4 : nullptr, nullptr};
+      if ((rc = order_outputs(ctx, L, st, lo, hi))) return rc;
     }
     // Pairs with an empty image still go through the re-rank step: with no
     // candidates every query comes out unmatched, as in the reference.  Their

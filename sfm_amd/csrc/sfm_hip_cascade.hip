@@ -66,7 +66,10 @@ hipEvent_t take_event(sfm_hip_ctx* ctx) {
     return e;
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  if (hipEventCreate(&e) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
   return e;
 }
 
@@ -126,68 +129,90 @@ int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
   // the same image may be named twice: hash it once
   std::sort(ims.begin(), ims.end());
   ims.erase(std::unique(ims.begin(), ims.end()), ims.end());
+  // Nothing is touched before every image has passed: a refused call leaves all hashes as they were.
+  for (Image* im : ims)
+    if ((size_t)im->n > (size_t)MAX_IMAGE_ROWS)
+      return fail(ctx, SFM_HIP_ERR_INVALID, "the cascade-hash path takes images of at most 262,144 descriptors");
   // an image that is hashed again may still be read by queued matching work
   bool rehash = false;
   for (Image* im : ims) rehash = rehash || im->hash_block;
   if (rehash)
     if (int rc = sync_all(ctx)) return rc;
   hipStream_t st = ctx->upload_stream;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->cascade_projection + (size_t)PROJ_MEAN_AT, mean128, DIM * sizeof(float),
-                              hipMemcpyHostToDevice, st));
-  std::vector<HashJob> jobs;
-  int blocks = 0;
-  for (Image* im : ims) {
-    free_image_hashes(*im);
-    const size_t n = (size_t)im->n;
-    if (n > (size_t)MAX_IMAGE_ROWS)
-      return fail(ctx, SFM_HIP_ERR_INVALID, "the cascade-hash path takes images of at most 262,144 descriptors");
-    const size_t recs_bytes = align_up(std::max<size_t>(n, 1) * sizeof(HashRec), 256);
-    const size_t half_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(uint2), 256);
-    const size_t bkt_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(uint16_t), 256);
-    const size_t meta_bytes = align_up(std::max<size_t>(n, 1) * GROUPS * sizeof(HashMeta), 256);
-    const size_t off_bytes = align_up((size_t)GROUPS * (BUCKETS + 1) * sizeof(int32_t), 256);
-    hipError_t e = hipMalloc(&im->hash_block, recs_bytes + 2 * half_bytes + bkt_bytes + meta_bytes + off_bytes);
-    if (e != hipSuccess) {
-      im->hash_block = nullptr;
-      return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc hash records: ") + hipGetErrorString(e));
+  // New hashes are built in blocks of their own and become the images' hashes only after the
+  // kernels that fill them have finished; on any failure the new blocks are freed and the images
+  // keep what they had (valid older hashes, or none).
+  struct Fresh {
+    void* block = nullptr;
+    size_t recs_bytes = 0, half_bytes = 0, bkt_bytes = 0, meta_bytes = 0;
+  };
+  std::vector<Fresh> fresh(ims.size());
+  auto build = [&]() -> int {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->cascade_projection + (size_t)PROJ_MEAN_AT, mean128, DIM * sizeof(float),
+                                hipMemcpyHostToDevice, st));
+    std::vector<HashJob> jobs;
+    int blocks = 0;
+    for (size_t k = 0; k < ims.size(); k++) {
+      const Image* im = ims[k];
+      Fresh& f = fresh[k];
+      const size_t n = std::max<size_t>((size_t)im->n, 1);
+      f.recs_bytes = align_up(n * sizeof(HashRec), 256);
+      f.half_bytes = align_up(n * GROUPS * sizeof(uint2), 256);
+      f.bkt_bytes = align_up(n * GROUPS * sizeof(uint16_t), 256);
+      f.meta_bytes = align_up(n * GROUPS * sizeof(HashMeta), 256);
+      const size_t off_bytes = align_up((size_t)GROUPS * (BUCKETS + 1) * sizeof(int32_t), 256);
+      const hipError_t e = hipMalloc(&f.block, f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes + f.meta_bytes + off_bytes);
+      if (e != hipSuccess) {
+        f.block = nullptr;
+        return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc hash records: ") + hipGetErrorString(e));
+      }
+      char* at = (char*)f.block;
+      HashJob j;
+      j.d = im->d;
+      j.recs = (HashRec*)at;
+      j.glo = (uint2*)(at + f.recs_bytes);
+      j.ghi = (uint2*)(at + f.recs_bytes + f.half_bytes);
+      j.gbkt = (uint16_t*)(at + f.recs_bytes + 2 * f.half_bytes);
+      j.gmeta = (HashMeta*)(at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes);
+      j.offsets = (int32_t*)(at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes + f.meta_bytes);
+      j.n = im->n;
+      j.first_block = blocks;
+      blocks += (im->n + 63) / 64;
+      jobs.push_back(j);
     }
-    char* at = (char*)im->hash_block;
-    im->hash_recs = at;
-    at += recs_bytes;
-    im->hash_glo = at;
-    at += half_bytes;
-    im->hash_ghi = at;
-    at += half_bytes;
-    im->hash_gbkt = at;
-    at += bkt_bytes;
-    im->hash_gmeta = at;
-    at += meta_bytes;
-    im->hash_offsets = (int32_t*)at;
-    HashJob j;
-    j.d = im->d;
-    j.recs = (HashRec*)im->hash_recs;
-    j.glo = (uint2*)im->hash_glo;
-    j.ghi = (uint2*)im->hash_ghi;
-    j.gbkt = (uint16_t*)im->hash_gbkt;
-    j.gmeta = (HashMeta*)im->hash_gmeta;
-    j.offsets = im->hash_offsets;
-    j.n = im->n;
-    j.first_block = blocks;
-    blocks += (im->n + 63) / 64;
-    jobs.push_back(j);
-  }
-  Scratch table;
-  HIP_TRY(ctx, hipMalloc(&table.p, jobs.size() * sizeof(HashJob)));
-  HIP_TRY(ctx, hipMemcpyAsync(table.p, jobs.data(), jobs.size() * sizeof(HashJob), hipMemcpyHostToDevice, st));
-  if (blocks > 0) {
-    hipLaunchKernelGGL(k_ch_hash, dim3((unsigned)blocks), dim3(256), 0, st, (const HashJob*)table.p, (int)jobs.size(),
-                       (const float*)ctx->cascade_projection);
+    Scratch table;
+    HIP_TRY(ctx, hipMalloc(&table.p, jobs.size() * sizeof(HashJob)));
+    HIP_TRY(ctx, hipMemcpyAsync(table.p, jobs.data(), jobs.size() * sizeof(HashJob), hipMemcpyHostToDevice, st));
+    if (blocks > 0) {
+      hipLaunchKernelGGL(k_ch_hash, dim3((unsigned)blocks), dim3(256), 0, st, (const HashJob*)table.p, (int)jobs.size(),
+                         (const float*)ctx->cascade_projection);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_ch_group, dim3(GROUPS, (unsigned)jobs.size()), dim3(64), 0, st, (const HashJob*)table.p);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return SFM_HIP_OK;
+  };
+  if (const int rc = build()) {
+    (void)hipStreamSynchronize(st);   // nothing may still write into the blocks that are freed now
+    for (Fresh& f : fresh)
+      if (f.block) (void)hipFree(f.block);
+    return rc;
   }
-  hipLaunchKernelGGL(k_ch_group, dim3(GROUPS, (unsigned)jobs.size()), dim3(64), 0, st, (const HashJob*)table.p);
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  ctx->cascade_stats.images_hashed += (uint64_t)jobs.size();
+  for (size_t k = 0; k < ims.size(); k++) {
+    Image* im = ims[k];
+    const Fresh& f = fresh[k];
+    free_image_hashes(*im);
+    char* at = (char*)f.block;
+    im->hash_block = f.block;
+    im->hash_recs = at;
+    im->hash_glo = at + f.recs_bytes;
+    im->hash_ghi = at + f.recs_bytes + f.half_bytes;
+    im->hash_gbkt = at + f.recs_bytes + 2 * f.half_bytes;
+    im->hash_gmeta = at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes;
+    im->hash_offsets = (int32_t*)(at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes + f.meta_bytes);
+  }
+  ctx->cascade_stats.images_hashed += (uint64_t)ims.size();
   return SFM_HIP_OK;
 }
 
@@ -353,6 +378,22 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     if (ctx->profiling) {
       t0 = take_event(ctx);
       t1 = take_event(ctx);
+      if (!t0 || !t1) {   // no events to be had: this batch runs untimed
+        if (t0) ctx->event_pool.push_back(t0);
+        if (t1) ctx->event_pool.push_back(t1);
+        t0 = t1 = nullptr;
+      }
+    }
+    // results land in call order even when calls share output memory (order_outputs, ctx.hpp)
+    if (L.tail_pending) {   // this lane's previous batch: same stream, already ordered
+      L.tail_pending = false;
+    }
+    {
+      const char* const lo[5] = {(const char*)(out_counts + done), (const char*)(out_lhs_idx + o), (const char*)(out_rhs_idx + o),
+                                 out_dist ? (const char*)(out_dist + o) : nullptr, (const char*)(out_defaults + done)};
+      const char* const hi[5] = {lo[0] + (size_t)count * 4, lo[1] + out_words * 4, lo[2] + out_words * 4,
+                                 lo[3] ? lo[3] + out_words * 4 : nullptr, lo[4] + (size_t)count * 4};
+      if ((rc = order_outputs(ctx, L, st, lo, hi))) return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(L.cascade_tables.p, hp, table_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipEventRecord(L.stage_free[slot], st));
@@ -393,6 +434,8 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
         if (out_dist) HIP_TRY(ctx, hipMemcpyAsync(out_dist + o, k_dist, out_words * 4, hipMemcpyDeviceToHost, st));
       }
     }
+    HIP_TRY(ctx, hipEventRecord(L.tail_done, st));
+    L.tail_pending = true;
     ctx->cascade_stats.pairs += (uint64_t)count;
     done += count;
   }

@@ -241,3 +241,64 @@ def test_image_size_limit_of_the_cascade_path(matcher):
     with pytest.raises(binding.SfmHipError, match="262,144"):
         matcher.cascade_hash_images([0, 1], np.zeros(128, np.float32))
     matcher.drop_all()
+
+
+def test_refused_hashing_leaves_earlier_hashes_usable(matcher):
+    """A call that names a small image and one beyond the size limit is refused as a whole: the
+    small image keeps the hashes it had (matching it still gives the oracle's result), and an image
+    that never had hashes still has none (matching it is refused, not run on unfilled memory)."""
+    a, b = synth.make_repetitive_set(2, 1500, 0.6, 2, seed=19, sigma=0.002)
+    big = np.zeros((262145, 128), np.float32)
+    images = {0: a, 1: b}
+    _upload(matcher, {0: a, 1: b, 2: big, 3: a[:40]})
+    pairs = [(0, 1)]
+    mean = matcher.cascade_prepare(pairs)
+    before = _check_pairs(matcher, images, pairs, True)
+    assert before > 20
+    for ids in ([0, 2], [2, 0], [3, 2]):
+        with pytest.raises(binding.SfmHipError, match="262,144"):
+            matcher.cascade_hash_images(ids, mean)
+    assert _check_pairs(matcher, images, pairs, True) == before
+    with pytest.raises(binding.SfmHipError, match="hash"):
+        matcher.cascade_match_pairs([(3, 0)], True)
+    matcher.drop_all()
+
+
+def test_calls_in_flight_that_reuse_output_buffers_land_in_call_order(matcher):
+    """Consecutive cascade batches run on two streams in turn.  Two sets of output buffers used in
+    turn by eight calls in flight, a big pair (slow) followed by small ones: each set must end up
+    holding its LAST call's result."""
+    import ctypes
+    from sfm_amd.binding import _Pinned
+    lib = sfm_amd.library()
+    imgs = synth.make_repetitive_set(4, 20000, 0.5, 2, seed=27, sigma=0.002)
+    images = {0: imgs[0], 1: imgs[1], 2: imgs[2][:400], 3: imgs[3][:300]}
+    _upload(matcher, images)
+    calls = [(2, 3), (3, 2), (0, 1), (1, 0), (2, 3), (3, 2), (3, 2), (2, 3)]
+    everything = sorted(set(calls))
+    matcher.cascade_prepare(everything)
+    mean = _oracle_mean(images, everything)
+    stride = 20000
+    sets = [[_Pinned(lib, s, t) for s, t in (((1,), np.int32), ((1,), np.int32), ((1, stride), np.int32),
+                                             ((1, stride), np.int32), ((1, stride), np.float32))] for _ in range(2)]
+    try:
+        for k, pair in enumerate(calls):
+            p = np.array([pair], np.int64)
+            dfl, cnt, lhs, rhs, dist = sets[k & 1]
+            rc = lib.sfm_hip_cascade_match_pairs(matcher._h, p.ctypes.data, 1, 1, dfl.ptr, cnt.ptr, lhs.ptr, rhs.ptr,
+                                                 dist.ptr, stride)
+            assert rc == 0, lib.sfm_hip_last_error(matcher._h)
+        matcher.sync()
+        for which in (0, 1):
+            a, b = [p for k, p in enumerate(calls) if (k & 1) == which][-1]
+            dfl, cnt, lhs, rhs, dist = sets[which]
+            end, el, er, ed = cascade.match_pair(images[a], images[b], mean, True)
+            c = int(cnt.array[0])
+            assert (int(dfl.array[0]), lhs.array[0, :c].tolist(), rhs.array[0, :c].tolist()) == (end, el.tolist(), er.tolist())
+            assert dist.array[0, :c].view(np.uint32).tolist() == ed.view(np.uint32).tolist()
+    finally:
+        matcher.sync()
+        for bufs in sets:
+            for b in bufs:
+                b.free()
+        matcher.drop_all()

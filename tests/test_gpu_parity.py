@@ -431,3 +431,32 @@ def test_two_nearest_in_one_column_list_and_ratio_at_the_threshold(matcher):
     l, r, d = check_pair(matcher, X, Y, True)
     assert 0.1 * n < len(l) < 0.9 * n
     assert matcher.stats()["rescanned_queries"] > 0
+
+
+@pytest.mark.parametrize("ratio", [0.99999, 1.0, 0.999])
+def test_near_equal_neighbours_with_ratio_next_to_one(matcher, ratio):
+    """Ratios within 1e-5 of 1: the two nearest of a query are almost equally far, in both directions
+    (neighbouring rows of the first image share a column list, columns 32 apart share a lane's row
+    list).  A candidate that reaches the exact re-rank under two keys must count once, or the second
+    distance would equal the first and the test below the ratio would fail where the reference's
+    passes."""
+    rng = np.random.default_rng(10)
+    n = 192
+    Y = synth.rootsift_rows(n, 523)
+    X = synth.rootsift_rows(64 * n, 524)
+    for i in range(n):
+        e1 = rng.standard_normal(128)
+        e1 /= np.linalg.norm(e1)
+        e2 = rng.standard_normal(128)
+        e2 -= e2.dot(e1) * e1
+        e2 /= np.linalg.norm(e2)
+        delta = 0.05 + 0.1 * rng.random()
+        eps = (rng.random() - 0.5) * 4e-5
+        X[64 * i] = (Y[i] + delta * (1 + eps) * e1).astype(np.float32)
+        X[64 * i + (1 if i % 2 else 32)] = (Y[i] + delta * e2).astype(np.float32)
+    l, r, d = check_pair(matcher, X, Y, True, ratio)
+    check_pair(matcher, X, Y, False, ratio)
+    l2, _, _ = check_pair(matcher, Y, X, True, ratio)
+    check_pair(matcher, Y, X, False, ratio)
+    if ratio == 0.99999:                        # the queries sit on both sides of this ratio
+        assert 0.2 * n < len(l) < n and 0.2 * n < len(l2) < n
