@@ -215,7 +215,8 @@ class SetJob:
 
     def run(self, m):
         """The whole shard through 64-pair calls, two sets of pinned outputs in turn: the GPU matches
-        call b while the host copies the compact lists of call b - 1 out.  Returns (counts, lhs, rhs)."""
+        call b, with call b + 1 queued behind it, while the host copies the compact lists of call
+        b - 1 out.  Returns (counts, lhs, rhs)."""
         counts = np.zeros(len(self.mine), np.int32)
         lhs_parts, rhs_parts = [], []
 
@@ -229,9 +230,9 @@ class SetJob:
         prev = None
         for lo in range(0, len(self.mine), PAIRS_PER_CALL):
             p = self.pairs[self.mine[lo:lo + PAIRS_PER_CALL]]
-            m.sync()                          # call b - 1 is complete (its outputs are the other set)
-            out = m.match_pairs_async(p, 0.8, True, stride=N_FEATURES)
+            out = m.match_pairs_async(p, 0.8, True, stride=N_FEATURES)   # queued behind call b - 1
             if prev is not None:
+                m.wait_outputs(prev[1][0])    # call b - 1 alone is complete; call b runs on
                 collect(*prev)
             prev = (lo, out)
         m.sync()

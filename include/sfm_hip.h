@@ -193,6 +193,14 @@ int sfm_hip_partition_pairs(const int64_t* pair_ids, int32_t n_pairs, const int6
  * brute_force_matcher.cc:67-68,83). */
 int sfm_hip_sync(sfm_hip_ctx* ctx);
 
+/* Wait until no queued call still has to write the host memory [out, out + bytes) -- typically the
+ * out_counts array of one call: that call's outputs are then valid although later calls, writing
+ * other memory, are still running.  This is the reference's future.get() for ONE pair's task
+ * (brute_force_matcher.cc:67-68), where sfm_hip_sync is the join of all of them: a host loop can
+ * keep a call queued behind the running one and still consume results call by call.  Calls of
+ * sfm_hip_match_pairs and sfm_hip_cascade_match_pairs are covered. */
+int sfm_hip_wait_outputs(sfm_hip_ctx* ctx, const void* out, size_t bytes);
+
 /* Pinned host memory for the output buffers. */
 void* sfm_hip_host_alloc(size_t bytes);
 void sfm_hip_host_free(void* p);

@@ -16,7 +16,7 @@ EXPORTS = (
     "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
     "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats", "sfm_hip_set_engine",
     "sfm_hip_upload_image_device", "sfm_hip_match_pair_noalloc", "sfm_hip_partition_pairs",
-    "sfm_hip_replicate_images",
+    "sfm_hip_replicate_images", "sfm_hip_wait_outputs",
     "sfm_hip_cascade_set_projection", "sfm_hip_cascade_column_sums", "sfm_hip_cascade_hash_images",
     "sfm_hip_cascade_get_hashes", "sfm_hip_cascade_match_pairs", "sfm_hip_cascade_reference_projection",
     "sfm_hip_cascade_image_order", "sfm_hip_cascade_prepare", "sfm_hip_cascade_get_stats",
@@ -84,6 +84,7 @@ def library():
     lib.sfm_hip_match_pair_noalloc.argtypes = [vp, i64, i64, ctypes.c_double, ctypes.c_int, vp, vp, vp, vp]
     lib.sfm_hip_partition_pairs.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp]
     lib.sfm_hip_replicate_images.argtypes = [vp, i32, vp, vp, vp, i32, ctypes.POINTER(ReplicateTimes)]
+    lib.sfm_hip_wait_outputs.argtypes = [vp, vp, ctypes.c_size_t]
     lib.sfm_hip_sync.argtypes = [vp]
     lib.sfm_hip_host_alloc.argtypes = [ctypes.c_size_t]
     lib.sfm_hip_host_alloc.restype = vp
@@ -281,6 +282,12 @@ class Matcher:
 
     def sync(self):
         self._check(self._lib.sfm_hip_sync(self._h), "sfm_hip_sync")
+
+    def wait_outputs(self, array):
+        """Wait until no queued call still has to write `array` (a pinned output array, or a view of
+        one, as match_pairs_async returns them); calls that write other memory keep running."""
+        a = np.asarray(array)
+        self._check(self._lib.sfm_hip_wait_outputs(self._h, a.ctypes.data, a.nbytes), "sfm_hip_wait_outputs")
 
     def pinned(self, shape, dtype):
         """A pinned host array from the library's allocator (free() it, or leave it to the process)."""

@@ -759,6 +759,25 @@ int sfm_hip_sync(sfm_hip_ctx* ctx) {
   return sync_all(ctx);
 }
 
+int sfm_hip_wait_outputs(sfm_hip_ctx* ctx, const void* out, size_t bytes) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (!out || bytes == 0) return SFM_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const char* lo = (const char*)out;
+  const char* hi = lo + bytes;
+  // An unfinished batch is always the latest of its lane (a lane is taken again only after its
+  // previous batch has finished), and the lane remembers what that batch writes.
+  for (Lane& L : ctx->lanes) {
+    if (!L.tail_pending) continue;
+    bool overlap = false;
+    for (int a = 0; a < 5 && !overlap; a++) overlap = L.out_lo[a] && lo < L.out_hi[a] && L.out_lo[a] < hi;
+    if (!overlap) continue;
+    HIP_TRY(ctx, hipEventSynchronize(L.tail_done));
+    L.tail_pending = false;
+  }
+  return SFM_HIP_OK;
+}
+
 void* sfm_hip_host_alloc(size_t bytes) {
   void* p = nullptr;
   if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;

@@ -60,8 +60,8 @@ void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int
 
 // One GPU: upload the images its pairs touch, then match its shard of the pair list (indices into
 // jobs) in batches.
-// Two sets of pinned result buffers alternate, so the GPU works on batch b while this thread
-// turns batch b-1 into Match records.
+// Two sets of pinned result buffers alternate, so the GPU works on batch b (with batch b+1 queued
+// behind it) while this thread turns batch b-1 into Match records.
 void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<size_t>& shard, double ratio, bool cross,
                 int engine, Progress& progress, int helpers, sfm_hip_ctx* resident_ctx) {
   // resident_ctx: a context that already holds every image (replication by collective); this worker
@@ -172,14 +172,17 @@ void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<
       if (f) std::rethrow_exception(f);
   };
 
+  // The GPU always has the next batch queued behind the one it is working on: batch b + 1 is
+  // submitted (into the set of buffers that batch b - 1 has been collected from) before this thread
+  // waits for batch b alone and turns it into records.
   size_t which = 0;
   size_t prev = 0;
   upload_for(0, std::min(batch, n_jobs));
   submit(0, sets[which]);
   for (size_t b0 = batch; b0 < n_jobs; b0 += batch) {
     upload_for(b0, std::min(b0 + batch, n_jobs));                     // while batch 'prev' runs
-    if (sfm_hip_sync(ctx) != SFM_HIP_OK) fail(ctx, "sfm_hip_sync");   // batch 'prev' is complete
     submit(b0, sets[which ^ 1]);
+    if (sfm_hip_wait_outputs(ctx, sets[which].counts, batch * sizeof(int32_t)) != SFM_HIP_OK) fail(ctx, "sfm_hip_wait_outputs");
     collect(prev, sets[which]);
     prev = b0;
     which ^= 1;

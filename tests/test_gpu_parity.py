@@ -460,3 +460,31 @@ def test_near_equal_neighbours_with_ratio_next_to_one(matcher, ratio):
     check_pair(matcher, Y, X, False, ratio)
     if ratio == 0.99999:                        # the queries sit on both sides of this ratio
         assert 0.2 * n < len(l) < n and 0.2 * n < len(l2) < n
+
+
+def test_wait_outputs_makes_one_calls_results_valid(matcher):
+    """sfm_hip_wait_outputs: a host loop that keeps the next call queued behind the running one and
+    consumes results call by call, without ever draining the context."""
+    sizes = [700, 333, 1024, 512, 90, 2048]
+    imgs = [im[:n] for im, n in zip(synth.make_image_set(6, 2048, 0.5, seed=79), sizes)]
+    for i, im in enumerate(imgs):
+        matcher.upload(800 + i, im)
+    calls = [[(800 + a, 800 + b) for b in range(6) if b != a] for a in range(6)]     # five pairs per call
+    exp = {(a, b): oracle.match_pair(imgs[a - 800], imgs[b - 800], 0.8, True, threads=4) for c in calls for a, b in c}
+    try:
+        prev = None
+        for call in calls + [None]:
+            out = matcher.match_pairs_async(call, 0.8, True, stride=2048) if call else None
+            if prev is not None:
+                pcall, (cnt, lhs, rhs, dist) = prev
+                matcher.wait_outputs(cnt)
+                for k, pair in enumerate(pcall):
+                    c = int(cnt[k])
+                    assert_same((lhs[k, :c].astype(np.int64), rhs[k, :c].astype(np.int64), dist[k, :c].copy()), exp[pair],
+                                "pair %s" % (pair,))
+            prev = (call, out)
+        matcher.wait_outputs(np.zeros(4, np.int32))      # memory no call writes: returns at once
+    finally:
+        matcher.sync()
+        for i in range(6):
+            matcher.drop(800 + i)
