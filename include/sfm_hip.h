@@ -153,8 +153,8 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
  *     context run one after the other, in call order, also relative to sfm_hip_match_pairs calls that
  *     write the same outputs;
  *   - every call on a GPU uses that GPU's one array: calls through two contexts of the same GPU
- *     (or from two processes' worth of threads on one context) that overlap in time race.  Calls
- *     on different GPUs do not interfere. */
+ *     that overlap in time race (as do two host threads driving one context, which no entry point
+ *     allows).  Calls on different GPUs, and in different processes, do not interfere. */
 #define SFM_HIP_NOALLOC_MAX_ROWS 8192
 int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t second_image, double ratio,
                                int cross_check, int32_t* out_count, int32_t* out_lhs_idx,
