@@ -186,24 +186,38 @@ class SetJob:
     correspondences), cut for `world` ranks by the library's partition.  Images are generated per
     rank, only those its shard names."""
 
-    def __init__(self, n_images, rank, world):
+    def __init__(self, n_images, rank, world, replication="host"):
+        """replication "host": this rank generates and uploads the images its shard names;
+        "collective": it generates its 1/world share of ALL images, uploads that, and one RCCL
+        all-gather over xGMI hands every share to every GPU (BASELINE.json configs[4])."""
         from sfm_amd import synth
-        from sfm_amd.distributed import exhaustive_pairs, images_of, partition
-        self.n_images, self.rank, self.world = n_images, rank, world
+        from sfm_amd.distributed import exhaustive_pairs, images_of, partition, shard_bounds
+        self.n_images, self.rank, self.world, self.replication = n_images, rank, world, replication
         self.ids = list(range(n_images))
         self.rows = {i: N_FEATURES for i in self.ids}
         self.pairs = exhaustive_pairs(self.ids)
         self.shards = partition(self.pairs, self.rows, world)
         self.mine = self.shards[rank]
-        self.need = images_of(self.pairs, self.mine) if len(self.mine) else []
-        self.images_per_rank = [len(images_of(self.pairs, s)) if len(s) else 0 for s in self.shards]
+        if replication == "collective":
+            lo, hi = shard_bounds(n_images, rank, world)
+            self.need = self.ids[lo:hi]
+            self.images_per_rank = [n_images] * world
+        else:
+            self.need = images_of(self.pairs, self.mine) if len(self.mine) else []
+            self.images_per_rank = [len(images_of(self.pairs, s)) if len(s) else 0 for s in self.shards]
         pool = synth.scene_pool(PLANTED, SET_SEED)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(8, host_cores()[0])) as ex:
             made = list(ex.map(lambda i: synth.scene_image(i, N_FEATURES, pool, SET_SEED), self.need))
         self.images = dict(zip(self.need, made))
 
-    def upload(self, m):
+    def upload(self, m, coll_device=None):
+        if self.replication == "collective":
+            from sfm_amd.distributed import replicate_images
+            replicate_images(m, self.images, self.rank, self.world,
+                             device=coll_device if coll_device is not None and coll_device.type == "cuda" else None,
+                             method="collective")
+            return
         for i in self.need:
             m.upload(i, self.images[i])
 
@@ -269,7 +283,7 @@ def whole_job_leg(m, job, barrier, max_over_ranks, device, engine):
     m.drop_all()
     barrier()
     t0 = time.perf_counter()
-    job.upload(m)
+    job.upload(m, device)
     m.sync()
     barrier()
     t_up = max_over_ranks(time.perf_counter() - t0)
@@ -300,7 +314,8 @@ def whole_job_leg(m, job, barrier, max_over_ranks, device, engine):
     flop = 2.0 * N_FEATURES * N_FEATURES * 128
     leg = {"workload": "exhaustive matching, %d synthetic images x %d features, %d pairs, ratio 0.8 + cross-check, "
                        "%d-pair calls of sfm_hip_match_pairs" % (job.n_images, N_FEATURES, n, PAIRS_PER_CALL),
-           "n_gpus": job.world, "pairs": n, "images_uploaded_per_rank": job.images_per_rank,
+           "n_gpus": job.world, "pairs": n, "replication": job.replication,
+           "images_resident_per_rank": job.images_per_rank,
            "uploads_s": t_up, "match_s": t_match, "gather_s": t_gather,
            "pairs_per_s_matching": n / t_match, "pairs_per_s_with_uploads_and_gather": n / (t_up + t_match + t_gather),
            "value": n / (t_up + t_match + t_gather), "unit": "pairs/s",
@@ -333,6 +348,39 @@ def batched_leg(m, engine, n_pairs=64, calls=24):
     return {"pairs_per_call": n_pairs, "calls": calls, "engine": engine, "value": value, "unit": "pairs/s",
             "ms_per_pair": elapsed / (calls * n_pairs) * 1e3,
             "frac_of_fp32_mfma_peak_end_to_end": value * 2.0 * N_FEATURES * N_FEATURES * 128 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "roofline": roofline(st, engine, None)}
+
+
+def large_pair_leg(m, engine, n=16384, steps=60):
+    """One pair at the image size of BASELINE.json configs[4] (16384 x 16384 descriptors), one pair per call:
+    four times the work of the headline pair per launch, chunks of 2,048 columns."""
+    from sfm_amd import synth
+    m.set_engine(engine)
+    A, B, truth = synth.make_pair(n, n, n // 2, seed=4096)
+    m.upload(20, A)
+    m.upload(21, B)
+    pair = np.array([[20, 21]], np.int64)
+    for _ in range(20):
+        out = m.match_pairs_async(pair, 0.8, True, stride=n)
+    m.sync()
+    cnt = int(out[0][0])
+    found = len(set(zip(out[1][0, :cnt].tolist(), out[2][0, :cnt].tolist())) & set(map(tuple, truth.tolist())))
+    m.set_profiling(True)
+    m.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.match_pairs_async(pair, 0.8, True, stride=n)
+    m.sync()
+    elapsed = time.perf_counter() - t0
+    st = m.stats()
+    m.set_profiling(False)
+    m.drop(20)
+    m.drop(21)
+    value = steps / elapsed
+    return {"workload": "single synthetic pair, %dx%d 128-d float descriptors, ratio 0.8 + cross-check" % (n, n),
+            "engine": engine, "value": value, "unit": "pairs/s", "ms_per_step": elapsed / steps * 1e3,
+            "matches_found": cnt, "planted_found": found, "rescanned_queries_per_pair": st["rescanned_queries"] / max(1, st["pairs"]),
+            "frac_of_fp32_mfma_peak_end_to_end": value * 2.0 * n * n * 128 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "roofline": roofline(st, engine, None)}
 
 
@@ -379,6 +427,12 @@ def main():
     ap.add_argument("--set-images", type=int, default=0,
                     help="images of the exhaustive job: N > 1 default 500 (BASELINE.json configs[3]), "
                          "N = 1 whole_job leg default 100 (configs[2])")
+    ap.add_argument("--set-features", type=int, default=8192,
+                    help="N > 1: features per image of the exhaustive job (16384 with --set-images 1000: configs[4])")
+    ap.add_argument("--replication", choices=["host", "collective"], default="host",
+                    help="N > 1: how the job's descriptors reach the GPUs: every rank uploads its shard's images "
+                         "from its host memory, or every rank uploads a 1/N share of all images and an RCCL "
+                         "all-gather over xGMI replicates them (configs[4]'s descriptor broadcast)")
     ap.add_argument("--no-whole-job", action="store_true",
                     help="do not run the whole exhaustive job (uploads + matching + gather) after the timed region")
     ap.add_argument("--no-batched", action="store_true",
@@ -421,16 +475,28 @@ def main():
     # streams are given them in order of creation.  The context's four streams must not share one
     # (a tail kernel queued in front of a distance kernel delays it); RCCL's streams, idle during the
     # timed region, may share as they like.
+    global N_FEATURES, PLANTED
     m = sfm_amd.Matcher(local_rank if dist_on else 0)
     m.set_engine(args.engine)
     t0 = time.perf_counter()
     if dist_on:
-        job = SetJob(args.set_images or 500, rank, world)
+        if args.set_features % 256 or args.set_features <= 0:
+            raise SystemExit("--set-features must be a positive multiple of 256")
+        N_FEATURES, PLANTED = args.set_features, args.set_features // 2
+        job = SetJob(args.set_images or 500, rank, world, args.replication)
         if not len(job.mine):
             raise SystemExit("rank %d has no pairs: fewer pairs than ranks" % rank)
         setup_s = time.perf_counter() - t0
         t0 = time.perf_counter()
-        job.upload(m)
+        if args.replication == "host":
+            job.upload(m)
+        else:   # the collective needs the process group, which comes after the context's streams are in use
+            for i in (0, 1):
+                m.upload(10**9 + i, np.zeros((256, 128), np.float32))
+            for _ in range(4):
+                m.match_pairs_async(np.array([[10**9, 10**9 + 1]], np.int64), 0.8, True, stride=256)
+            m.sync()
+            m.drop_all()
         upload_s = time.perf_counter() - t0
         per_step = PAIRS_PER_CALL
         step_no = [0]
@@ -449,9 +515,10 @@ def main():
 
         def step():
             return m.match_pairs_async(pairs, 0.8, True, stride=N_FEATURES)
-    for _ in range(4):   # every stream of the context has been used once (queues are bound at first use)
-        step()
-    m.sync()
+    if not (dist_on and args.replication == "collective"):
+        for _ in range(4):   # every stream of the context has been used once (queues are bound at first use)
+            step()
+        m.sync()
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -459,6 +526,10 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if args.replication == "collective":
+            t0 = time.perf_counter()
+            job.upload(m, coll_device)
+            upload_s = time.perf_counter() - t0
 
     def barrier():
         if dist_on:
@@ -541,14 +612,16 @@ def main():
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "exhaustive matching of %d synthetic images x %d features (%d pairs, BASELINE.json "
-                                       "configs[3]%s), ratio 0.8 + cross-check, pair list cut into %d shards of equal cost "
+                                       "configs[%s]%s), ratio 0.8 + cross-check, pair list cut into %d shards of equal cost "
                                        "(2-D blocks of the pair triangle); a step = one %d-pair call of sfm_hip_match_pairs "
                                        "per GPU on the next pairs of its shard"
                                        % (job.n_images, N_FEATURES, len(job.pairs),
-                                          "" if job.n_images == 500 else ": a subset", world, PAIRS_PER_CALL),
+                                          "4" if N_FEATURES == 16384 else "3",
+                                          "" if (job.n_images, N_FEATURES) in ((500, 8192), (1000, 16384)) else ": a subset",
+                                          world, PAIRS_PER_CALL),
                            "engine": args.engine, "pairs_per_step_per_gpu": per_step, "planted_matches": PLANTED,
                            "matches_last_call_min_max": [int(cnt.min()), int(cnt.max())],
-                           "images_resident_per_gpu": job.images_per_rank,
+                           "images_resident_per_gpu": job.images_per_rank, "replication": job.replication,
                            "parallelism": "pairs sharded over ranks, one process per GPU, no collective on the data path"},
                 "frac_of_fp32_mfma_peak_end_to_end": value / world * flop_per_pair / (PEAK_FP32_MFMA_TFLOPS * 1e12),
                 "rescanned_queries_per_pair": st["rescanned_queries"] / max(1, st["pairs"]),
@@ -607,6 +680,11 @@ def main():
             line["batched"] = batched_leg(m, args.engine)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, B, got)
+        if not args.no_batched and per_step == 1:
+            try:
+                line["pair_16k"] = large_pair_leg(m, args.engine)
+            except Exception as e:   # an extra, never the reason the headline line is lost
+                line["pair_16k"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_whole_job:
             try:
                 m.set_engine(args.engine)
