@@ -1056,6 +1056,9 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
 #if defined(SFM_K2_STOP_AFTER) && SFM_K2_STOP_AFTER == 0
   return;   // diagnostic build: the launch alone
 #endif
+#ifdef SFM_RERANK_PRIO
+  if constexpr (PP == 0) __builtin_amdgcn_s_setprio(SFM_RERANK_PRIO);
+#endif
   const PairDev& P = pairs[blockIdx.y];
   const int dir = blockIdx.z;
   const int nq = dir == 0 ? P.na : P.nb;
@@ -1503,21 +1506,25 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
 // Cross-check (brute_force_matcher.cc:64-80) and ordered compaction.  A forward
 // match (i -> j) is kept when the reverse direction matched j back to i, or
 // when j has no surviving reverse match and i == 0 (the reference's map_[j]
-// default-inserts 0).  One workgroup of 1024 threads per pair; every thread owns
+// default-inserts 0).  One workgroup of THREADS threads per pair; every thread owns
 // eight consecutive rows per sweep, so output order is ascending row order.
-__global__ __launch_bounds__(1024) void k_cross_compact(const PairDev* __restrict__ pairs, int cross_check,
+// THREADS = 1024 for batches; 256 (one wave per SIMD, next to no LDS) for launches of a few pairs,
+// whose workgroup then fits beside a workgroup of k_distance_topk instead of holding up the one
+// that the next launch wants to place on its compute unit.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_cross_compact(const PairDev* __restrict__ pairs, int cross_check,
                                                         int32_t* __restrict__ out_counts,
                                                         int32_t* __restrict__ out_lhs,
                                                         int32_t* __restrict__ out_rhs,
                                                         float* __restrict__ out_dist, int64_t out_stride) {
-  __shared__ int wsum[16];
+  __shared__ int wsum[THREADS / 64];
   __shared__ int base_s;
   const PairDev& P = pairs[blockIdx.x];
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   const size_t ob = (size_t)P.out_slot * (size_t)out_stride;
   if (tid == 0) base_s = 0;
   __syncthreads();
-  for (int i0 = 0; i0 < P.na; i0 += 8192) {
+  for (int i0 = 0; i0 < P.na; i0 += 8 * THREADS) {
     const int ib = i0 + tid * 8;     // fwd arrays are padded to a multiple of 128 rows: vector loads stay in bounds
     int j[8];
     float d[8];
@@ -1568,7 +1575,7 @@ __global__ __launch_bounds__(1024) void k_cross_compact(const PairDev* __restric
     __syncthreads();
     if (tid == 0) {
       int s = base_s;
-      for (int k = 0; k < 16; k++) s += wsum[k];
+      for (int k = 0; k < THREADS / 64; k++) s += wsum[k];
       base_s = s;
     }
     __syncthreads();

@@ -598,7 +598,11 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       HIP_TRY(ctx, hipMemsetAsync(hp[k].rowpart, 0xFF, pl.rowpart_words * 4, st));
       HIP_TRY(ctx, hipMemsetAsync(hp[k].colpart, 0xFF, pl.colpart_words * 4, st));
     }
+#ifdef SFM_ABLATE_TAIL   // diagnostic build: distance kernels only (the outputs are not written)
+    const int max_q = 0;
+#else
     const int max_q = cross_check ? std::max(max_na, max_nb) : max_na;
+#endif
     if (max_q > 0) {
       const dim3 grid((max_q + RR_QUERIES - 1) / RR_QUERIES, count, cross_check ? 2 : 1);
       const int eng = ctx->engine == SFM_HIP_ENGINE_F16X3 ? ENGINE_F16X3 : ENGINE_F32;
@@ -610,9 +614,15 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
         hipLaunchKernelGGL(k_rerank<0>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev);
       HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_cross_compact, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
-                       k_rhs, k_dist, out_stride);
+#if !defined(SFM_ABLATE_TAIL) && !defined(SFM_ABLATE_COMPACT)
+    if (count >= ctx->n_cu / 4)
+      hipLaunchKernelGGL(k_cross_compact<1024>, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
+                         k_rhs, k_dist, out_stride);
+    else   // a few pairs: workgroups small enough to sit beside the next launch's distance workgroups
+      hipLaunchKernelGGL(k_cross_compact<256>, dim3(count), dim3(256), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
+                         k_rhs, k_dist, out_stride);
     HIP_TRY(ctx, hipGetLastError());
+#endif
 
     if (!direct) {
       HIP_TRY(ctx, hipMemcpyAsync(out_counts + done, k_counts, (size_t)count * 4, hipMemcpyDeviceToHost, st));
@@ -745,7 +755,7 @@ int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t se
       hipLaunchKernelGGL(k_rerank<0>, grid, dim3(256), 0, ds, (const PairDev*)d_pair, ratio, eng, ctx->rescanned_dev);
     HIP_TRY(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_cross_compact, dim3(1), dim3(1024), 0, ds, (const PairDev*)d_pair, cross_check ? 1 : 0, k_count,
+  hipLaunchKernelGGL(k_cross_compact<256>, dim3(1), dim3(256), 0, ds, (const PairDev*)d_pair, cross_check ? 1 : 0, k_count,
                      k_lhs, k_rhs, k_dist ? k_dist : d_dist, (int64_t)SFM_HIP_NOALLOC_MAX_ROWS);
   HIP_TRY(ctx, hipGetLastError());
   ctx->stats.pairs += 1;

@@ -7,5 +7,6 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/ab
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form "$@" \
-  -shared -o tools/ab/$name.so sfm_amd/csrc/sfm_hip_capi.hip sfm_amd/csrc/sfm_hip_cascade.hip sfm_amd/csrc/sfm_hip_geometry.hip
+  -shared -o tools/ab/$name.so sfm_amd/csrc/sfm_hip_capi.hip sfm_amd/csrc/sfm_hip_cascade.hip sfm_amd/csrc/sfm_hip_geometry.hip \
+  sfm_amd/csrc/sfm_hip_replicate.hip sfm_amd/csrc/sfm_hip_partition.cc -ldl
 echo tools/ab/$name.so
