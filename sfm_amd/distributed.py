@@ -60,7 +60,9 @@ def gather_flat(per_pair, columns, shards, rank, world, group=None, device=None,
     """
     import torch
     import torch.distributed as dist
-    per_pair = np.ascontiguousarray(per_pair, dtype=np.int32).reshape(len(shards[rank]), -1)
+    per_pair = np.ascontiguousarray(per_pair, dtype=np.int32)
+    if per_pair.ndim != 2 or per_pair.shape[0] != len(shards[rank]):
+        raise ValueError("per_pair must be [pairs of this rank's shard, k]")
     k, c = per_pair.shape[1], len(columns)
     total = int(per_pair[:, -1].sum()) if len(per_pair) else 0
     cols = np.empty((c, total), np.int32)

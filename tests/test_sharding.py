@@ -96,6 +96,11 @@ if rank == 0:
     print("SHARDING_OK", sum(len(g[0]) for g in got))
 else:
     assert got is None
+# fewer pairs than ranks: a rank with an empty shard still takes part in the gather
+few = exhaustive_pairs([10, 11])
+got1 = match_pairs_sharded(OracleMatcher(images), few, 0.8, True, rank, world, image_rows=rows)
+if rank == 0:
+    assert len(got1) == 1 and all(np.array_equal(x, y) for x, y in zip(got1[0], exp[0]))
 # the gather on its own, payload forced through several chunks, one rank with nothing to send
 fake = [np.arange(0, 9, 2), np.arange(1, 9, 2)] if world == 2 else None
 cnt = np.array([3 * q + 1 for q in fake[rank]], np.int32) if rank == 0 else np.zeros(4, np.int32)
