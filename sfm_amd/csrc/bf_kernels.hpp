@@ -390,13 +390,20 @@ __device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const f32x
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Which 1 KiB piece of the next stage leaves with step S of column tile CT (-1: none).
+#ifdef SFM_EARLY_PIECES
+// diagnostic build: all sixteen pieces in the first two column tiles, one every second step
+#define SFM_PIECE_AT(CT, S) ((CT) < 2 && (S) % 2 == 1 ? 8 * (CT) + (S) / 2 : -1)
+#else
+#define SFM_PIECE_AT(CT, S) ((S) % 4 == 1 ? 4 * (CT) + (S) / 4 : -1)
+#endif
 template <int ENGINE, int TOFF, int ROT, bool HAS_NEXT, int CT, int... S>
 __device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32x16& acc0, f32x16& acc1,
                                            const f32x4 (&a0)[16], const f32x4 (&a1)[16], f32x4 (&b)[3],
                                            const uint32_t (&X)[8], const StageFeed& feed,
                                            const uint32_t (&yvoff)[8]) {
   // piece 4 CT + S/4 of the next stage leaves with step S = 1, 5, 9, 13 of column tile CT
-  (pair_step<ENGINE, TOFF, S, ROT, HAS_NEXT, (S % 4 == 1 ? 4 * CT + S / 4 : -1)>(acc0, acc1, a0, a1, b, X, feed, yvoff),
+  (pair_step<ENGINE, TOFF, S, ROT, HAS_NEXT, SFM_PIECE_AT(CT, S)>(acc0, acc1, a0, a1, b, X, feed, yvoff),
    ...);
 }
 
@@ -533,7 +540,7 @@ __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x
   acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
   FoldState f{SENT, SENT};
-  (pipe_step<CT, S, FOLD, (CT < 3), (S % 4 == 1 ? 4 * CT + S / 4 : -1)>(acc0, acc1, a0, a1, b, X, feed, yvoff, p0, p1, tvp,
+  (pipe_step<CT, S, FOLD, (CT < 3), SFM_PIECE_AT(CT, S)>(acc0, acc1, a0, a1, b, X, feed, yvoff, p0, p1, tvp,
                                                                         L0, L1, f),
    ...);
   if constexpr (FOLD) {

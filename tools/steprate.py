@@ -1,6 +1,6 @@
 """Steady-state time per single-pair step (300 steps between two syncs, after 400 warm-up steps)."""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import sfm_amd
 from sfm_amd import synth
 m = sfm_amd.Matcher(0)
