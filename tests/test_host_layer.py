@@ -197,6 +197,30 @@ def test_gpu_stage_driver_three_shards_on_one_gpu(tmp_path, engine):
         assert rec["lx"].tolist() == [float(v) for v in l] and set(rec["ry"].tolist()) <= {float(b)}
 
 
+@pytest.mark.gpu
+def test_gpu_stage_driver_eight_shards_ragged_images(tmp_path):
+    """Eight shards (the partition an 8-GPU node gets: 2-D blocks of the pair triangle, cost-weighted)
+    forced onto the one GPU, over images of very different sizes, two of them empty: every pair of the
+    list comes back, each with the oracle's matches."""
+    exe = os.path.join(ROOT, "sfm_amd", "lib", "feature_match_main")
+    sizes = (600, 40, 0, 333, 600, 1, 257, 129, 512, 0, 64, 450, 90)
+    imgs = synth.make_image_set(len(sizes), 600, 0.5, seed=81)
+    images = {7 * i + 2: im[:n] for i, (im, n) in enumerate(zip(imgs, sizes))}
+    kps = {i: synth.keypoints(len(d), i) for i, d in images.items()}
+    path = str(tmp_path / "sfm_data.bin")
+    write_sfm_bin(path, images, kps)
+    env = dict(os.environ, SFM_HIP_OVERSUBSCRIBE="1")
+    out = subprocess.run([exe, path, "--devices", "8"], check=True, env=env, stdout=subprocess.PIPE, text=True).stdout
+    n_pairs = len(sizes) * (len(sizes) - 1) // 2
+    assert "Need To Match %d Pairs." % n_pairs in out and out.count("\nFinish ") == n_pairs
+    data = read_sfm_bin(path)
+    ids = sorted(images)
+    assert sorted(data["matches"]) == [(a, b) for k, a in enumerate(ids) for b in ids[k + 1:]]
+    for (a, b), rec in data["matches"].items():
+        l, r, _ = oracle.match_pair(images[a], images[b], 0.8, True)
+        assert rec["li"].tolist() == l.tolist() and rec["ri"].tolist() == r.tolist(), (a, b)
+
+
 def _cascade_expected(images, pairs, cross):
     from oracle import cascade
     whole, _, _ = cascade.match_set(images, pairs, cross)
