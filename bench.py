@@ -136,6 +136,7 @@ def cascade_leg(m, with_cpu, n_images=32, reps=40):
            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                         "traffic": traffic, "kernel": "one batch of %d pairs: k_ch_walk_count .. k_ch_compact" % len(pairs),
                         "bytes_per_batch": st["match_bytes"] / st["match_launches"],
+                        "traffic_over_algorithmic": (traffic / (st["match_bytes"] / st["match_launches"])) if traffic else None,
                         "avg_batch_ms": st["match_ms"] / st["match_launches"],
                         "bytes_per_pair": st["match_bytes"] / (reps * len(pairs))}}
     if with_cpu:
