@@ -208,7 +208,7 @@ void sfm_hip_host_free(void* p);
 /* Profiling: when enabled, one launch in eight of the distance/top-k kernel (the first after
  * sfm_hip_reset_stats or sfm_hip_get_stats among them) is bracketed by HIP events on the stream it
  * runs on.  Distance kernels run one after the other on a stream of their own and each batch's short
- * tail kernels on one of four other streams, so a launch never shares the chip with another launch
+ * tail kernels on one of two other streams, so a launch never shares the chip with another launch
  * of its kind; the start event is a packet of its own in front of the kernel and costs a few
  * microseconds, which is why not every launch carries one.  sfm_hip_get_stats() waits for the
  * queued work and folds the durations into distance_ms. */

@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
   run_j("J6 as J, small kernel 1 KiB LDS, 144 registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<256, 144>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
   run_j("J7 as J, small kernel 3.5 KiB LDS, 104 registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<896, 104>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
   run_j("J8 as J, small kernel 6 KiB LDS, few registers", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<1536, 0>), dim3(256), dim3(256), 0, st, dchain, dout, hops); });
-  run_j("J9 as J, one workgroup of 1024 threads, 512 B LDS", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<128, 0>), dim3(1), dim3(256), 0, st, dchain, dout, hops); });
+  run_j("J9 as J, one workgroup of 256 threads, 512 B LDS", [&](hipStream_t st) { hipLaunchKernelGGL((k_small<128, 0>), dim3(1), dim3(256), 0, st, dchain, dout, hops); });
   timed("M as K, start/stop events and nothing else", [&] {
     for (int i = 0; i < steps; i++) { k1x(s_main, es[i], ee[i]); } });
   timed("N as M, stop events only", [&] {
