@@ -245,7 +245,8 @@ class SetJob:
         prev = None
         for lo in range(0, len(self.mine), PAIRS_PER_CALL):
             p = self.pairs[self.mine[lo:lo + PAIRS_PER_CALL]]
-            out = m.match_pairs_async(p, 0.8, True, stride=N_FEATURES)   # queued behind call b - 1
+            # queued behind call b - 1; no distances, as the C++ matcher class calls it (a Match record has none)
+            out = m.match_pairs_async(p, 0.8, True, stride=N_FEATURES, want_dist=False)
             if prev is not None:
                 m.wait_outputs(prev[1][0])    # call b - 1 alone is complete; call b runs on
                 collect(*prev)

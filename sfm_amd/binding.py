@@ -268,15 +268,17 @@ class Matcher:
         self._turn ^= 1
         return self._bufs[4 * self._turn:4 * self._turn + 4]
 
-    def match_pairs_async(self, pairs, ratio=0.8, cross_check=True, stride=None):
-        """Queue the pairs; returns the pinned output arrays (valid after sync())."""
+    def match_pairs_async(self, pairs, ratio=0.8, cross_check=True, stride=None, want_dist=True):
+        """Queue the pairs; returns the pinned output arrays (valid after sync()).  want_dist=False
+        passes out_dist = NULL, as the C++ matcher class does (the reference's Match record holds no
+        distance): the distance array returned is then not written."""
         p = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
         if stride is None:
             stride = max([self.image_size(i) for i in set(p[:, 0].tolist())] + [1])
         cnt, lhs, rhs, dist = self._outputs(p.shape[0], int(stride))
         self._check(self._lib.sfm_hip_match_pairs(self._h, p.ctypes.data, p.shape[0], float(ratio),
-                                                  int(bool(cross_check)), cnt.ptr, lhs.ptr, rhs.ptr, dist.ptr,
-                                                  int(stride)), "sfm_hip_match_pairs")
+                                                  int(bool(cross_check)), cnt.ptr, lhs.ptr, rhs.ptr,
+                                                  dist.ptr if want_dist else None, int(stride)), "sfm_hip_match_pairs")
         n = p.shape[0]
         return cnt.array[:n], lhs.array[:n], rhs.array[:n], dist.array[:n]
 

@@ -1047,7 +1047,7 @@ constexpr int RR_SQ_STRIDE = 132;    // words per row of squares (128 + 4: confl
 // the re-rank still takes its turn on the SIMD; beside the fp16 ones it does overlap.)
 template <int PP>
 __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ pairs, double ratio, int engine,
-                                                   unsigned long long* __restrict__ rescanned) {
+                                                   unsigned long long* __restrict__ rescanned, int want_dist) {
   static_assert(PP == 0 || PP == 64, "two variants");
   __shared__ __attribute__((aligned(16))) float sq[PP > 0 ? PP * RR_SQ_STRIDE : DIM];
   __shared__ uint32_t cand[RR_QUERIES * NCAND];
@@ -1055,6 +1055,7 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
   __shared__ float res_r[RR_QUERIES * NCAND];
   __shared__ int unsafe_q[RR_QUERIES];
   __shared__ int mode[RR_QUERIES];
+  __shared__ uint32_t acc_col[RR_QUERIES];   // the column of a query accepted from its keys alone
   __shared__ int n_unsafe;
   __shared__ Top2 wave_part[4];
   __shared__ uint16_t live[256];   // PP == 0: the (query, candidate) pairs that need a distance, densely
@@ -1197,7 +1198,10 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
         if ((int)c0 >= no) md = RR_FULL;   // cannot happen for a finite key; the full merge sorts it out
       }
       if (md != RR_FULL) {
-        cand[tid + 0] = c0;
+        // An accepted query's exact distance is part of the output only if the caller asked for
+        // distances (the reference's Match record holds none): without them it needs no row loads.
+        acc_col[ql] = c0;
+        cand[tid + 0] = (md == RR_ACCEPT && !want_dist) ? SENT : c0;
         cand[tid + 1] = SENT;
         cand[tid + 2] = SENT;
         cand[tid + 3] = SENT;
@@ -1319,7 +1323,11 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
         else if ((double)sqrtf(float_above(hi0)) < ratio * (double)sqrtf(float_below(rest_lo))) md = RR_ACCEPT;
       }
       if (md == RR_REJECT) c0 = SENT;
-      if (md != RR_FULL) c1 = c2 = c3 = SENT;
+      if (md != RR_FULL) {
+        c1 = c2 = c3 = SENT;
+        acc_col[ql] = c0;
+        if (md == RR_ACCEPT && !want_dist) c0 = SENT;
+      }
       cand[tid + 0] = c0;
       cand[tid + 1] = c1;
       cand[tid + 2] = c2;
@@ -1429,8 +1437,8 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
     int32_t* best = dir == 0 ? P.fwd_best : P.rev_best;
     float* dist = dir == 0 ? P.fwd_dist : P.rev_dist;
     const bool accept = mode[tid] == RR_ACCEPT;
-    best[q] = accept ? (int32_t)cand[tid * NCAND] : -1;
-    dist[q] = accept ? sqrtf(res_r[tid * NCAND]) : 0.0f;
+    best[q] = accept ? (int32_t)acc_col[tid] : -1;
+    dist[q] = (accept && want_dist) ? sqrtf(res_r[tid * NCAND]) : 0.0f;
   } else if (tid < RR_QUERIES && q0 + tid < nq) {
     const int q = q0 + tid;
     Top2 t;

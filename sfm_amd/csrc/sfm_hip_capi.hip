@@ -609,9 +609,9 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       // enough workgroups for several per compute unit: the variant with coalesced row loads;
       // otherwise the one that fits beside a distance workgroup
       if ((size_t)grid.x * grid.y * grid.z >= (size_t)4 * ctx->n_cu)
-        hipLaunchKernelGGL(k_rerank<64>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev);
+        hipLaunchKernelGGL(k_rerank<64>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev, out_dist ? 1 : 0);
       else
-        hipLaunchKernelGGL(k_rerank<0>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev);
+        hipLaunchKernelGGL(k_rerank<0>, grid, dim3(256), 0, st, dp, ratio, eng, ctx->rescanned_dev, out_dist ? 1 : 0);
       HIP_TRY(ctx, hipGetLastError());
     }
 #if !defined(SFM_ABLATE_TAIL) && !defined(SFM_ABLATE_COMPACT)
@@ -750,9 +750,11 @@ int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t se
   if (max_q > 0) {
     const dim3 grid((max_q + RR_QUERIES - 1) / RR_QUERIES, 1, cross_check ? 2 : 1);
     if ((size_t)grid.x * grid.z >= (size_t)4 * ctx->n_cu)
-      hipLaunchKernelGGL(k_rerank<64>, grid, dim3(256), 0, ds, (const PairDev*)d_pair, ratio, eng, ctx->rescanned_dev);
+      hipLaunchKernelGGL(k_rerank<64>, grid, dim3(256), 0, ds, (const PairDev*)d_pair, ratio, eng, ctx->rescanned_dev,
+                         out_dist ? 1 : 0);
     else
-      hipLaunchKernelGGL(k_rerank<0>, grid, dim3(256), 0, ds, (const PairDev*)d_pair, ratio, eng, ctx->rescanned_dev);
+      hipLaunchKernelGGL(k_rerank<0>, grid, dim3(256), 0, ds, (const PairDev*)d_pair, ratio, eng, ctx->rescanned_dev,
+                         out_dist ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
   }
   hipLaunchKernelGGL(k_cross_compact<256>, dim3(1), dim3(256), 0, ds, (const PairDev*)d_pair, cross_check ? 1 : 0, k_count,

@@ -488,3 +488,32 @@ def test_wait_outputs_makes_one_calls_results_valid(matcher):
         matcher.sync()
         for i in range(6):
             matcher.drop(800 + i)
+
+
+def test_calls_without_distances_return_the_same_matches(matcher):
+    """out_dist = NULL (what the C++ matcher class passes: the reference's Match record holds no
+    distance) lets the re-rank skip the exact distance of every match its keys already decide; the
+    index lists must not change.  A 64-pair call (the batch variant of the re-rank) and single pairs."""
+    imgs = [im[:n] for im, n in zip(synth.make_image_set(12, 2048, 0.5, seed=83), [2048, 1500, 2048, 700, 2048, 2048, 1, 1024, 2048, 333, 2048, 2000])]
+    for i, im in enumerate(imgs):
+        matcher.upload(900 + i, im)
+    pairs = [(900 + a, 900 + b) for a in range(12) for b in range(12) if a != b][:64]
+    try:
+        for cross in (True, False):
+            for call in (pairs, pairs[:1], pairs[5:7]):
+                with_d = [tuple(x.copy() for x in t) for t in matcher.match_pairs(call, 0.8, cross)]
+                cnt, lhs, rhs, _ = matcher.match_pairs_async(call, 0.8, cross, stride=2048, want_dist=False)
+                matcher.sync()
+                for k, (l, r, d) in enumerate(with_d):
+                    c = int(cnt[k])
+                    assert lhs[k, :c].tolist() == l.tolist() and rhs[k, :c].tolist() == r.tolist(), (call[k], cross)
+        for a, b in pairs[:6]:
+            exp = oracle.match_pair(imgs[a - 900], imgs[b - 900], 0.8, True, threads=4)
+            cnt, lhs, rhs, _ = matcher.match_pairs_async([(a, b)], 0.8, True, stride=2048, want_dist=False)
+            matcher.sync()
+            c = int(cnt[0])
+            assert lhs[0, :c].tolist() == exp[0].tolist() and rhs[0, :c].tolist() == exp[1].tolist()
+    finally:
+        matcher.sync()
+        for i in range(12):
+            matcher.drop(900 + i)
