@@ -105,6 +105,7 @@ struct sfm_hip_ctx {
   bool profiling = false;
   std::vector<sfm_host::TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
+  std::vector<void*> retired;                   // outgrown work-space buffers, freed at the next drain
   sfm_hip_stats stats{};
 
   hipStream_t upload_stream = nullptr;
@@ -148,20 +149,31 @@ inline int sync_all(sfm_hip_ctx* ctx) {
   for (hipStream_t t : ctx->tail_streams)
     if (t) HIP_TRY(ctx, hipStreamSynchronize(t));
   for (Lane& l : ctx->lanes) l.tail_pending = false;
+  for (void* p : ctx->retired) (void)hipFree(p);   // work-space buffers replaced by larger ones since the last drain
+  ctx->retired.clear();
   return SFM_HIP_OK;
 }
 
 inline int ensure(sfm_hip_ctx* ctx, Lane& L, DevBuf& b, size_t bytes) {
+  (void)L;
   if (b.bytes >= bytes) return SFM_HIP_OK;
-  // the old buffer may still be in use by work queued on its lane or on the distance stream
-  if (ctx->distance_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->distance_stream));
-  HIP_TRY(ctx, hipStreamSynchronize(L.stream));
-  if (b.p) HIP_TRY(ctx, hipFree(b.p));
+  // The old buffer may still be in use by work queued on its lane or on the distance stream.
+  // Waiting for that work here would leave the GPU idle while the new buffer is allocated, and
+  // hipFree waits for the whole device anyway: the old buffer is set aside and freed the next time
+  // the context is drained (sync_all) or destroyed.
+  if (b.p) ctx->retired.push_back(b.p);
   b.p = nullptr;
   b.bytes = 0;
   size_t want = bytes + bytes / 4;
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
+    // memory is short: give back what was set aside (which needs the queued work finished) and ask for less
+    if (ctx->distance_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->distance_stream));
+    for (hipStream_t t : ctx->tail_streams)
+      if (t) HIP_TRY(ctx, hipStreamSynchronize(t));
+    for (void* p : ctx->retired) (void)hipFree(p);
+    ctx->retired.clear();
     want = bytes;
     HIP_TRY(ctx, hipMalloc(&b.p, want));
   }

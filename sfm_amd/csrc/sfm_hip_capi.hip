@@ -233,6 +233,7 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   for (hipStream_t t : ctx->tail_streams)
     if (t) (void)hipStreamSynchronize(t);
   for (auto& kv : ctx->images) free_image(kv.second);
+  for (void* p : ctx->retired) (void)hipFree(p);
   for (Lane& l : ctx->lanes) {
     for (DevBuf* b : {&l.tables_dev, &l.rowpart, &l.colpart, &l.best, &l.out_dev, &l.cascade_tables, &l.cascade_slots, &l.cascade_lists})
       if (b->p) (void)hipFree(b->p);
