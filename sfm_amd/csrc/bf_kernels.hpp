@@ -329,6 +329,11 @@ __device__ __forceinline__ void anchor16(uint32_t (&x)[16]) {
                "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
 }
 
+// B fragments in flight per lane: a fragment is fetched two steps ahead of its use, so three register
+// sets rotate.  (A fourth set, so that a fetch never lands in the set the previous step has just read,
+// changed nothing: 137.9 us per step either way.)
+constexpr int NFRAG = 3;
+
 // Step S of a tile pair: fetch B fragment S+2, retire fragment S, then the matrix instructions
 // that consume it for each of the wave's two row tiles.  TOFF = byte offset of the column tile
 // inside its stage buffer; ROT: fragment s lives in b[(s + ROT) % 3]; HAS_NEXT: the next column
@@ -351,18 +356,18 @@ struct StageFeed {
 
 template <int ENGINE, int TOFF, int S, int ROT, bool HAS_NEXT, int PIECE>
 __device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const f32x4 (&a0)[16], const f32x4 (&a1)[16],
-                                          f32x4 (&b)[3], const uint32_t (&X)[8], const StageFeed& feed,
+                                          f32x4 (&b)[NFRAG], const uint32_t (&X)[8], const StageFeed& feed,
                                           const uint32_t (&yvoff)[8]) {
   if constexpr (S + 2 < 16) {
-    lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(S + 2 + ROT) % 3], X[(S + 2) & 7]);
+    lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(S + 2 + ROT) % NFRAG], X[(S + 2) & 7]);
     lds_wait<2>();
   } else if constexpr (HAS_NEXT) {
-    lds_read16<TOFF + 32 * DIM * 4>(b[(S + 2 + ROT) % 3], X[S + 2 - 16]);
+    lds_read16<TOFF + 32 * DIM * 4>(b[(S + 2 + ROT) % NFRAG], X[S + 2 - 16]);
     lds_wait<2>();
   } else {
     lds_wait<15 - S>();
   }
-  const f32x4 bs = b[(S + ROT) % 3];
+  const f32x4 bs = b[(S + ROT) % NFRAG];
   if constexpr (ENGINE == ENGINE_F32) {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S].x, bs.x, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S].x, bs.x, acc1, 0, 0, 0);
@@ -399,7 +404,7 @@ __device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const f32x
 #endif
 template <int ENGINE, int TOFF, int ROT, bool HAS_NEXT, int CT, int... S>
 __device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32x16& acc0, f32x16& acc1,
-                                           const f32x4 (&a0)[16], const f32x4 (&a1)[16], f32x4 (&b)[3],
+                                           const f32x4 (&a0)[16], const f32x4 (&a1)[16], f32x4 (&b)[NFRAG],
                                            const uint32_t (&X)[8], const StageFeed& feed,
                                            const uint32_t (&yvoff)[8]) {
   // piece 4 CT + S/4 of the next stage leaves with step S = 1, 5, 9, 13 of column tile CT
@@ -422,30 +427,54 @@ __device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLi
 // One column tile (32 columns) against the wave's 64 rows: 2 x 65 MFMAs, then the vector
 // epilogue for both accumulator tiles, then each lane's column list (over its half-wave's 32 rows)
 // is parked in LDS.
+#ifdef SFM_K1_STAMPS
+#define SFM_FOLD_CYCLES_PARAM , unsigned long long& g_fold_cycles
+#define SFM_FOLD_CYCLES_ARG , stamp_fold_cycles
+#else
+#define SFM_FOLD_CYCLES_PARAM
+#define SFM_FOLD_CYCLES_ARG
+#endif
 template <int ENGINE, int CT>
 __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
-                                          f32x4 (&b)[3], const uint32_t (&X)[8], uint32_t tv, LaneLists& L0,
+                                          f32x4 (&b)[NFRAG], const uint32_t (&X)[8], uint32_t tv, LaneLists& L0,
                                           LaneLists& L1, uint32_t lowc, int h, uint32_t* cb, const StageFeed& feed,
-                                          const uint32_t (&yvoff)[8]) {
+                                          const uint32_t (&yvoff)[8] SFM_FOLD_CYCLES_PARAM) {
   constexpr int TOFF = CT * 32 * DIM * 4;
-  if constexpr (CT == 0) {
-    lds_read16<TOFF>(b[0], X[0]);
-    lds_read16<TOFF>(b[1], X[1]);
-  }
+#ifdef SFM_K1_STAMPS
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  // (the first two fragments of a stage's first column tile are requested at the top of the stage,
+  // before the previous stage's column lists are merged: their trip through LDS then runs beside that work)
   f32x16 zero;
 #pragma unroll
   for (int i = 0; i < 16; i++) zero[i] = 0.0f;
   f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
   f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
-  pair_steps<ENGINE, TOFF, CT % 3, (CT < 3), CT>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X, feed,
+  pair_steps<ENGINE, TOFF, (16 * CT) % NFRAG, (CT < 3), CT>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X, feed,
                                                  yvoff);
 
   uint32_t cl0 = SENT, cl1 = SENT;
 #ifdef SFM_ABLATE_FOLD
   asm volatile("" ::"v"(acc0), "v"(acc1));   // diagnostic build: accumulators stay live, lists untouched
 #else
+#ifdef SFM_K1_STAMPS
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+  g_fold_cycles += (tf0 - tm0) << 32;   // high half: the matrix section of the tile pair
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   tile_fold<0>(acc0, tv, L0, cl0, cl1);
   tile_fold<1>(acc1, tv, L1, cl0, cl1);
+#ifdef SFM_K1_STAMPS
+  anchor16(L0.r0); anchor16(L0.r1);
+  anchor16(L1.r0); anchor16(L1.r1);
+  asm volatile("" : "+v"(cl0), "+v"(cl1));
+  __builtin_amdgcn_sched_barrier(0);
+  g_fold_cycles += __builtin_amdgcn_s_memtime() - tf0;
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
   // every lane parks its list (over its half-wave's 32 rows of the column); the eight lists of a
   // column -- four waves, two half-waves -- are merged once per stage
@@ -487,20 +516,20 @@ __device__ __forceinline__ void fold_elems(std::integer_sequence<int, E...>, con
 
 template <int CT, int S, bool FOLD, bool HAS_NEXT, int PIECE>
 __device__ __forceinline__ void pipe_step(f32x16& acc0, f32x16& acc1, const f32x4 (&a0)[16], const f32x4 (&a1)[16],
-                                          f32x4 (&b)[3], const uint32_t (&X)[8], const StageFeed& feed,
+                                          f32x4 (&b)[NFRAG], const uint32_t (&X)[8], const StageFeed& feed,
                                           const uint32_t (&yvoff)[8], const f32x16& p0, const f32x16& p1, uint32_t tvp,
                                           LaneLists& L0, LaneLists& L1, FoldState& f) {
   constexpr int TOFF = CT * 32 * DIM * 4;
   if constexpr (S + 2 < 16) {
-    lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(16 * CT + S + 2) % 3], X[(S + 2) & 7]);
+    lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(16 * CT + S + 2) % NFRAG], X[(S + 2) & 7]);
     lds_wait<2>();
   } else if constexpr (HAS_NEXT) {
-    lds_read16<TOFF + 32 * DIM * 4>(b[(16 * CT + S + 2) % 3], X[S + 2 - 16]);
+    lds_read16<TOFF + 32 * DIM * 4>(b[(16 * CT + S + 2) % NFRAG], X[S + 2 - 16]);
     lds_wait<2>();
   } else {
     lds_wait<15 - S>();
   }
-  const f16x8 frag = __builtin_bit_cast(f16x8, b[(16 * CT + S) % 3]);
+  const f16x8 frag = __builtin_bit_cast(f16x8, b[(16 * CT + S) % NFRAG]);
   if constexpr ((S & 1) == 0) {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S]), frag, acc1, 0, 0, 0);
@@ -527,7 +556,7 @@ __device__ __forceinline__ void pipe_step(f32x16& acc0, f32x16& acc1, const f32x
 template <int CT, bool FOLD, int... S>
 __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x16& acc0, f32x16& acc1,
                                           const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
-                                          f32x4 (&b)[3], const uint32_t (&X)[8], const StageFeed& feed,
+                                          f32x4 (&b)[NFRAG], const uint32_t (&X)[8], const StageFeed& feed,
                                           const uint32_t (&yvoff)[8], const f32x16& p0, const f32x16& p1, uint32_t tvp,
                                           LaneLists& L0, LaneLists& L1, uint32_t lowc, uint32_t* cbp) {
   if constexpr (CT == 0) {
@@ -565,15 +594,21 @@ __device__ __forceinline__ void stage_columns_out(uint32_t cbaddr, int hh, __amd
                                                   uint32_t soff, uint32_t plane_bytes) {
   asm volatile("" : "+v"(cbaddr));
   const lds_u32* cb = (const lds_u32*)cbaddr;
-  uint32_t k0 = cb[0], k1 = cb[64], k2 = SENT;
+  // all eight entries are requested before the first is used: one trip through LDS, not two
+  uint32_t e0[4], e1[4];
+#pragma unroll
+  for (int li = 0; li < 4; li++) {       // (wave, half-wave) = (0,0), (0,1), (1,0), (1,1) relative to the first
+    e0[li] = cb[(li >> 1) * 4 * 2 * 64 + (li & 1) * 32];
+    e1[li] = cb[(li >> 1) * 4 * 2 * 64 + (li & 1) * 32 + 64];
+  }
+  asm volatile("" : "+v"(e0[0]), "+v"(e1[0]), "+v"(e0[1]), "+v"(e1[1]), "+v"(e0[2]), "+v"(e1[2]), "+v"(e0[3]), "+v"(e1[3]));
+  uint32_t k0 = e0[0], k1 = e1[0], k2 = SENT;
   uint32_t second = k1;
 #pragma unroll
-  for (int li = 1; li < 4; li++) {       // (wave, half-wave) = (0,1), (1,0), (1,1) relative to the first
-    const uint32_t a = cb[(li >> 1) * 4 * 2 * 64 + (li & 1) * 32];
-    const uint32_t b = cb[(li >> 1) * 4 * 2 * 64 + (li & 1) * 32 + 64];
-    insert3(k0, k1, k2, a);
-    insert3(k0, k1, k2, b);
-    second = second < b ? second : b;
+  for (int li = 1; li < 4; li++) {
+    insert3(k0, k1, k2, e0[li]);
+    insert3(k0, k1, k2, e1[li]);
+    second = second < e1[li] ? second : e1[li];
   }
   const uint32_t p0 = other_half(k0), p1 = other_half(k1), p2 = other_half(k2), ps = other_half(second);
   insert3(k0, k1, k2, p0);
@@ -752,10 +787,26 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 4] = __builtin_amdgcn_s_memtime();
 #endif
 
+#ifdef SFM_K1_STAMPS
+  unsigned long long stamp_dma_wait = 0, stamp_barrier_wait = 0;   // summed over the stages, this wave
+  unsigned long long stamp_fold_cycles = 0;                        // summed over the tile pairs (fp32 engine)
+  unsigned long long stamp_head = 0;                               // stage entry to its first tile pair
+#endif
   // Chunks hold a multiple of 256 columns, so stages come in pairs and each stage body is
   // compiled for a fixed LDS buffer.
   auto stage_body = [&](auto UC, int gg) __attribute__((always_inline)) {
     constexpr int u = decltype(UC)::value;
+#ifdef SFM_K1_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long th0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    f32x4 b[NFRAG];
+    const uint32_t (&X)[8] = u == 0 ? X0 : X1;
+    if constexpr (ENGINE == ENGINE_F32) {
+      lds_read16<0>(b[0], X[0]);
+      lds_read16<0>(b[1], X[1]);
+    }
     float bn[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ct++) bn[ct] = h == 0 ? 1.0f : scaled_norm(nbn[ct]);
@@ -774,13 +825,16 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     uint32_t tv = (uint32_t)(4 * gg);
     asm volatile("" : "+v"(tv));   // a VGPR, so that the row key is one v_and_or_b32
     uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 2) * 64 + l;
-    f32x4 b[3];
-    const uint32_t (&X)[8] = u == 0 ? X0 : X1;
     if constexpr (ENGINE == ENGINE_F32) {
-      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 128, feed, yvoff);
-      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 128, feed, yvoff);
-      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 128, feed, yvoff);
-      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 128, feed, yvoff);
+#ifdef SFM_K1_STAMPS
+      __builtin_amdgcn_sched_barrier(0);
+      stamp_head += __builtin_amdgcn_s_memtime() - th0;
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
     } else {
       constexpr auto STEPS = std::make_integer_sequence<int, 16>{};
       f32x16 e0, e1, o0, o1;   // accumulators of the even and of the odd column tiles
@@ -798,8 +852,18 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     }
     // The next stage's LDS-DMA must have landed before anyone passes the barrier; the
     // compiler does not always drain it for __syncthreads(), so wait explicitly.
+#ifdef SFM_K1_STAMPS
+    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    const unsigned long long tb2 = __builtin_amdgcn_s_memtime();
+    stamp_dma_wait += tb1 - tb0;
+    stamp_barrier_wait += tb2 - tb1;
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // next stage landed; everyone done reading this one; column lists parked
+#endif
   };
   // Chunks hold a multiple of 256 columns, so stages come in pairs and each stage body is
   // compiled for a fixed LDS buffer.
@@ -812,6 +876,8 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 
 #ifdef SFM_K1_STAMPS
   if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 9] = stamp_fold_cycles;   // high half: matrix sections, low half: folds
+  if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 6] = (stamp_head << 32) | ((stamp_dma_wait + stamp_barrier_wait) & 0xFFFFFFFFull);
 #endif
   // row lists: through LDS (the stage buffers are free now), one thread per row
   uint32_t* rowbuf = reinterpret_cast<uint32_t*>(smem);

@@ -67,6 +67,17 @@ int main(int argc, char** argv) {
       std::sort(a.begin(), a.end()); std::sort(b2.begin(), b2.end()); std::sort(c.begin(), c.end());
       printf("   start->A issued med %.0f | A landed med %.0f | A read+scaled med %.0f\n", a[nblk/2], b2[nblk/2], c[nblk/2]); }
     printf("   prologue med %.0f max %.0f | row merge med %.0f max %.0f cycles\n", pro[nblk/2], pro.back(), mer[nblk/2], mer.back());
+    { // clock seen by each workgroup: cycle counter against the 100 MHz real-time counter, same compute unit
+      std::vector<double> ghz, us;
+      for (size_t b = 0; b < nblk; b++) { const double rt = (double)(st[10*b+3] - st[10*b+1]); if (rt > 0) { ghz.push_back((double)(st[10*b+2] - st[10*b]) / rt * 0.1); us.push_back(rt / 100.0); } }
+      std::sort(ghz.begin(), ghz.end()); std::sort(us.begin(), us.end());
+      if (!ghz.empty()) printf("   per workgroup: cycle counter / real time = %.3f GHz (median; min %.3f max %.3f), lifetime %.1f us median\n", ghz[ghz.size()/2], ghz.front(), ghz.back(), us[us.size()/2]); }
+    { std::vector<double> dw, bw; for (size_t b = 0; b < nblk; b++) { dw.push_back((double)(st[10*b+9] >> 32)); bw.push_back((double)(st[10*b+9] & 0xFFFFFFFFull)); }
+      std::sort(dw.begin(), dw.end()); std::sort(bw.begin(), bw.end());
+      printf("   wave 0, summed over the kernel: matrix sections of the tile pairs med %.0f max %.0f | folding accumulators into the lists med %.0f max %.0f cycles\n", dw[nblk/2], dw.back(), bw[nblk/2], bw.back()); }
+    { std::vector<double> hd, wt; for (size_t b = 0; b < nblk; b++) { hd.push_back((double)(st[10*b+6] >> 32)); wt.push_back((double)(st[10*b+6] & 0xFFFFFFFFull)); }
+      std::sort(hd.begin(), hd.end()); std::sort(wt.begin(), wt.end());
+      printf("   wave 0, summed over the stages: stage entry to first tile pair med %.0f | stage-end waits med %.0f cycles\n", hd[nblk/2], wt[nblk/2]); }
     std::sort(dur.begin(), dur.end()); std::sort(start.begin(), start.end());
     double real_us = (r1 - r0) / 100.0;   // 100 MHz
     printf("rep %d: event %.1f us | stamps: span %llu cyc, real %.1f us -> clock %.3f GHz | WG dur min %.0f med %.0f p90 %.0f max %.0f | start med %.0f p90 %.0f max %.0f | blocks %zu\n",
