@@ -626,7 +626,7 @@ __device__ __forceinline__ void stage_columns_out(uint32_t cbaddr, int hh, __amd
 #ifdef SFM_K1_STAMPS
 // Diagnostic build only (tools/k1_timing.hip): per workgroup clocks at start and end (cycle and
 // real-time counters), after the prologue, before the row merge, and at three points inside the
-// prologue (ten slots per workgroup).
+// prologue (twelve slots per workgroup).
 __device__ unsigned long long* g_stamps;
 #endif
 
@@ -636,12 +636,16 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   __shared__ __attribute__((aligned(1024))) char smem[LDS_TOTAL];
 #ifdef SFM_K1_STAMPS
   if (threadIdx.x == 0) {
-    g_stamps[10 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-    g_stamps[10 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    g_stamps[12 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    g_stamps[12 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
 
   const BlockDev blk = blocks[blockIdx.x];
+#ifdef SFM_K1_STAMPS
+  asm volatile("" ::"s"(blk.row0), "s"(blk.xrows));
+  if (threadIdx.x == 0) g_stamps[12 * blockIdx.x + 11] = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
@@ -684,12 +688,12 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   float sigma = 1.0f;   // ENGINE_F16X3: the accumulators hold distances times 2^(ex + ey)
   {
 #ifdef SFM_K1_STAMPS
-    if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 6] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) g_stamps[12 * blockIdx.x + 6] = __builtin_amdgcn_s_memtime();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef SFM_K1_STAMPS
-    if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 7] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) g_stamps[12 * blockIdx.x + 7] = __builtin_amdgcn_s_memtime();
 #endif
     // row 64w + 32t + r of the block sits 32 KiB * w + 16 KiB * t + 512 r into the two buffers
     const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)(w * 32768 + r * (DIM * 4));
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     }
     __syncthreads();   // everyone has its rows: the buffers may take the first column stages
 #ifdef SFM_K1_STAMPS
-    if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 8] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) g_stamps[12 * blockIdx.x + 8] = __builtin_amdgcn_s_memtime();
 #endif
   }
   // first column stage on its way
@@ -784,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // stage 0 landed
 #ifdef SFM_K1_STAMPS
-  if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 4] = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) g_stamps[12 * blockIdx.x + 4] = __builtin_amdgcn_s_memtime();
 #endif
 
 #ifdef SFM_K1_STAMPS
@@ -875,9 +879,9 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
                     (uint32_t)((nstages - 1) * SN * 4), plane_bytes);
 
 #ifdef SFM_K1_STAMPS
-  if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
-  if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 9] = stamp_fold_cycles;   // high half: matrix sections, low half: folds
-  if (threadIdx.x == 0) g_stamps[10 * blockIdx.x + 6] = (stamp_head << 32) | ((stamp_dma_wait + stamp_barrier_wait) & 0xFFFFFFFFull);
+  if (threadIdx.x == 0) g_stamps[12 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) g_stamps[12 * blockIdx.x + 9] = stamp_fold_cycles;   // high half: matrix sections, low half: folds
+  if (threadIdx.x == 0) g_stamps[12 * blockIdx.x + 10] = (stamp_head << 32) | ((stamp_dma_wait + stamp_barrier_wait) & 0xFFFFFFFFull);
 #endif
   // row lists: through LDS (the stage buffers are free now), one thread per row
   uint32_t* rowbuf = reinterpret_cast<uint32_t*>(smem);
@@ -939,8 +943,8 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 #ifdef SFM_K1_STAMPS
   __syncthreads();
   if (threadIdx.x == 0) {
-    g_stamps[10 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-    g_stamps[10 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    g_stamps[12 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    g_stamps[12 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
 }

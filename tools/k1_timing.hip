@@ -43,11 +43,11 @@ int main(int argc, char** argv) {
   }
   PairDev* dP; BlockDev* dB; unsigned long long* dS;
   size_t nblk = blocks.size();
-  CK(hipMalloc(&dP, sizeof(P))); CK(hipMalloc(&dB, sizeof(BlockDev) * nblk)); CK(hipMalloc(&dS, nblk * 80));
+  CK(hipMalloc(&dP, sizeof(P))); CK(hipMalloc(&dB, sizeof(BlockDev) * nblk)); CK(hipMalloc(&dS, nblk * 96));
   CK(hipMemcpy(dP, &P, sizeof(P), hipMemcpyHostToDevice)); CK(hipMemcpy(dB, blocks.data(), sizeof(BlockDev) * nblk, hipMemcpyHostToDevice));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dS, sizeof(dS)));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  std::vector<unsigned long long> st(nblk * 10);
+  std::vector<unsigned long long> st(nblk * 12);
   for (int rep = 0; rep < reps; rep++) {
     CK(hipEventRecord(e0, 0));
     if (engine) hipLaunchKernelGGL(k_distance_topk<ENGINE_F16X3>, dim3(nblk), dim3(256), 0, 0, dP, dB);
@@ -55,27 +55,29 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    CK(hipMemcpy(st.data(), dS, nblk * 80, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(st.data(), dS, nblk * 96, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull, t1 = 0, r0 = ~0ull, r1 = 0;
     std::vector<double> dur, start;
-    for (size_t b = 0; b < nblk; b++) { t0 = std::min(t0, st[10*b]); t1 = std::max(t1, st[10*b+2]); r0 = std::min(r0, st[10*b+1]); r1 = std::max(r1, st[10*b+3]); }
-    for (size_t b = 0; b < nblk; b++) { dur.push_back((double)(st[10*b+2] - st[10*b])); start.push_back((double)(st[10*b] - t0)); }
+    for (size_t b = 0; b < nblk; b++) { t0 = std::min(t0, st[12*b]); t1 = std::max(t1, st[12*b+2]); r0 = std::min(r0, st[12*b+1]); r1 = std::max(r1, st[12*b+3]); }
+    for (size_t b = 0; b < nblk; b++) { dur.push_back((double)(st[12*b+2] - st[12*b])); start.push_back((double)(st[12*b] - t0)); }
     std::vector<double> pro, mer;
-    for (size_t b = 0; b < nblk; b++) { pro.push_back((double)(st[10*b+4] - st[10*b])); mer.push_back((double)(st[10*b+2] - st[10*b+5])); }
+    for (size_t b = 0; b < nblk; b++) { pro.push_back((double)(st[12*b+4] - st[12*b])); mer.push_back((double)(st[12*b+2] - st[12*b+5])); }
     std::sort(pro.begin(), pro.end()); std::sort(mer.begin(), mer.end());
-    { std::vector<double> a, b2, c; for (size_t b = 0; b < nblk; b++) { a.push_back((double)(st[10*b+6]-st[10*b])); b2.push_back((double)(st[10*b+7]-st[10*b+6])); c.push_back((double)(st[10*b+8]-st[10*b+7])); }
+    { std::vector<double> d; for (size_t b = 0; b < nblk; b++) d.push_back((double)(st[12*b+11]-st[12*b]));
+      std::sort(d.begin(), d.end()); printf("   start->block descriptor in registers med %.0f min %.0f max %.0f\n", d[nblk/2], d.front(), d.back()); }
+    { std::vector<double> a, b2, c; for (size_t b = 0; b < nblk; b++) { a.push_back((double)(st[12*b+6]-st[12*b])); b2.push_back((double)(st[12*b+7]-st[12*b+6])); c.push_back((double)(st[12*b+8]-st[12*b+7])); }
       std::sort(a.begin(), a.end()); std::sort(b2.begin(), b2.end()); std::sort(c.begin(), c.end());
       printf("   start->A issued med %.0f | A landed med %.0f | A read+scaled med %.0f\n", a[nblk/2], b2[nblk/2], c[nblk/2]); }
     printf("   prologue med %.0f max %.0f | row merge med %.0f max %.0f cycles\n", pro[nblk/2], pro.back(), mer[nblk/2], mer.back());
     { // clock seen by each workgroup: cycle counter against the 100 MHz real-time counter, same compute unit
       std::vector<double> ghz, us;
-      for (size_t b = 0; b < nblk; b++) { const double rt = (double)(st[10*b+3] - st[10*b+1]); if (rt > 0) { ghz.push_back((double)(st[10*b+2] - st[10*b]) / rt * 0.1); us.push_back(rt / 100.0); } }
+      for (size_t b = 0; b < nblk; b++) { const double rt = (double)(st[12*b+3] - st[12*b+1]); if (rt > 0) { ghz.push_back((double)(st[12*b+2] - st[12*b]) / rt * 0.1); us.push_back(rt / 100.0); } }
       std::sort(ghz.begin(), ghz.end()); std::sort(us.begin(), us.end());
       if (!ghz.empty()) printf("   per workgroup: cycle counter / real time = %.3f GHz (median; min %.3f max %.3f), lifetime %.1f us median\n", ghz[ghz.size()/2], ghz.front(), ghz.back(), us[us.size()/2]); }
-    { std::vector<double> dw, bw; for (size_t b = 0; b < nblk; b++) { dw.push_back((double)(st[10*b+9] >> 32)); bw.push_back((double)(st[10*b+9] & 0xFFFFFFFFull)); }
+    { std::vector<double> dw, bw; for (size_t b = 0; b < nblk; b++) { dw.push_back((double)(st[12*b+9] >> 32)); bw.push_back((double)(st[12*b+9] & 0xFFFFFFFFull)); }
       std::sort(dw.begin(), dw.end()); std::sort(bw.begin(), bw.end());
       printf("   wave 0, summed over the kernel: matrix sections of the tile pairs med %.0f max %.0f | folding accumulators into the lists med %.0f max %.0f cycles\n", dw[nblk/2], dw.back(), bw[nblk/2], bw.back()); }
-    { std::vector<double> hd, wt; for (size_t b = 0; b < nblk; b++) { hd.push_back((double)(st[10*b+6] >> 32)); wt.push_back((double)(st[10*b+6] & 0xFFFFFFFFull)); }
+    { std::vector<double> hd, wt; for (size_t b = 0; b < nblk; b++) { hd.push_back((double)(st[12*b+10] >> 32)); wt.push_back((double)(st[12*b+10] & 0xFFFFFFFFull)); }
       std::sort(hd.begin(), hd.end()); std::sort(wt.begin(), wt.end());
       printf("   wave 0, summed over the stages: stage entry to first tile pair med %.0f | stage-end waits med %.0f cycles\n", hd[nblk/2], wt[nblk/2]); }
     std::sort(dur.begin(), dur.end()); std::sort(start.begin(), start.end());
