@@ -1591,11 +1591,15 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
 // Cross-check (brute_force_matcher.cc:64-80) and ordered compaction.  A forward
 // match (i -> j) is kept when the reverse direction matched j back to i, or
 // when j has no surviving reverse match and i == 0 (the reference's map_[j]
-// default-inserts 0).  One workgroup of THREADS threads per pair; every thread owns
-// eight consecutive rows per sweep, so output order is ascending row order.
-// THREADS = 1024 for batches; 256 (one wave per SIMD, next to no LDS) for launches of a few pairs,
-// whose workgroup then fits beside a workgroup of k_distance_topk instead of holding up the one
-// that the next launch wants to place on its compute unit.
+// default-inserts 0).  Every thread owns eight consecutive rows of a sweep of 8 x THREADS rows, so
+// output order is ascending row order.
+// THREADS = 1024 for batches: one workgroup per pair (grid (pairs, 1)) goes through the sweeps one
+// after the other.  THREADS = 256 (one wave per SIMD, next to no LDS) for launches of a few pairs,
+// whose workgroups then fit beside a workgroup of k_distance_topk instead of holding up the one
+// that the next launch wants to place on its compute unit; there the grid is (pairs, sweeps): a
+// workgroup writes one sweep and first counts what the sweeps before it keep (the same loads, all
+// in flight at once), so the pair takes one trip through its dependent loads instead of one per sweep.
+// The workgroup of the last sweep in the grid writes the pair's count.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_cross_compact(const PairDev* __restrict__ pairs, int cross_check,
                                                         int32_t* __restrict__ out_counts,
@@ -1603,17 +1607,18 @@ __global__ __launch_bounds__(THREADS) void k_cross_compact(const PairDev* __rest
                                                         int32_t* __restrict__ out_rhs,
                                                         float* __restrict__ out_dist, int64_t out_stride) {
   __shared__ int wsum[THREADS / 64];
+  __shared__ int wearlier[THREADS / 64];
   __shared__ int base_s;
   const PairDev& P = pairs[blockIdx.x];
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   const size_t ob = (size_t)P.out_slot * (size_t)out_stride;
-  if (tid == 0) base_s = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < P.na; i0 += 8 * THREADS) {
-    const int ib = i0 + tid * 8;     // fwd arrays are padded to a multiple of 128 rows: vector loads stay in bounds
-    int j[8];
-    float d[8];
-    bool keep[8];
+  constexpr int SWEEP = 8 * THREADS;
+  const bool one_sweep_each = gridDim.y > 1;
+  const int first = one_sweep_each ? (int)blockIdx.y * SWEEP : 0;
+  const int last = one_sweep_each ? min(P.na, first + SWEEP) : P.na;
+
+  // fwd arrays are padded to a multiple of 128 rows: vector loads stay in bounds
+  auto decide = [&](int ib, int (&j)[8], float (&d)[8], bool (&keep)[8]) {
     if (ib < P.na) {
       const int4 a = *reinterpret_cast<const int4*>(P.fwd_best + ib);
       const int4 b = *reinterpret_cast<const int4*>(P.fwd_best + ib + 4);
@@ -1636,6 +1641,33 @@ __global__ __launch_bounds__(THREADS) void k_cross_compact(const PairDev* __rest
       if (keep[k] && cross_check) keep[k] = rbv[k] == i || (rbv[k] < 0 && i == 0);
       cnt += keep[k] ? 1 : 0;
     }
+    return cnt;
+  };
+
+  // what the sweeps before this workgroup's keep (nothing when one workgroup does them all)
+  int earlier = 0;
+  for (int i0 = 0; i0 < min(first, P.na); i0 += SWEEP) {
+    int j[8];
+    float d[8];
+    bool keep[8];
+    earlier += decide(i0 + tid * 8, j, d, keep);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) earlier += __shfl_xor(earlier, o);
+  if (l == 0) wearlier[wv] = earlier;
+  __syncthreads();
+  if (tid == 0) {
+    int s = 0;
+    for (int k = 0; k < THREADS / 64; k++) s += wearlier[k];
+    base_s = s;
+  }
+  __syncthreads();
+  for (int i0 = first; i0 < last; i0 += SWEEP) {
+    const int ib = i0 + tid * 8;
+    int j[8];
+    float d[8];
+    bool keep[8];
+    const int cnt = decide(ib, j, d, keep);
     // exclusive scan of cnt over the workgroup
     int incl = cnt;
 #pragma unroll
@@ -1665,7 +1697,7 @@ __global__ __launch_bounds__(THREADS) void k_cross_compact(const PairDev* __rest
     }
     __syncthreads();
   }
-  if (tid == 0) out_counts[P.out_slot] = base_s;
+  if (tid == 0 && blockIdx.y == gridDim.y - 1) out_counts[P.out_slot] = base_s;
 }
 
 }  // namespace sfm

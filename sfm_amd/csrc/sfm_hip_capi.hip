@@ -619,9 +619,9 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     if (count >= ctx->n_cu / 4)
       hipLaunchKernelGGL(k_cross_compact<1024>, dim3(count), dim3(1024), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
                          k_rhs, k_dist, out_stride);
-    else   // a few pairs: workgroups small enough to sit beside the next launch's distance workgroups
-      hipLaunchKernelGGL(k_cross_compact<256>, dim3(count), dim3(256), 0, st, dp, cross_check ? 1 : 0, k_counts, k_lhs,
-                         k_rhs, k_dist, out_stride);
+    else   // a few pairs: workgroups small enough to sit beside the next launch's distance workgroups, one per sweep
+      hipLaunchKernelGGL(k_cross_compact<256>, dim3(count, (unsigned)std::max(1, (max_na + 2047) / 2048)), dim3(256), 0, st, dp,
+                         cross_check ? 1 : 0, k_counts, k_lhs, k_rhs, k_dist, out_stride);
     HIP_TRY(ctx, hipGetLastError());
 #endif
 
@@ -758,7 +758,8 @@ int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t se
                          out_dist ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_cross_compact<256>, dim3(1), dim3(256), 0, ds, (const PairDev*)d_pair, cross_check ? 1 : 0, k_count,
+  hipLaunchKernelGGL(k_cross_compact<256>, dim3(1, (unsigned)std::max(1, (pl.X->n + 2047) / 2048)), dim3(256), 0, ds,
+                     (const PairDev*)d_pair, cross_check ? 1 : 0, k_count,
                      k_lhs, k_rhs, k_dist ? k_dist : d_dist, (int64_t)SFM_HIP_NOALLOC_MAX_ROWS);
   HIP_TRY(ctx, hipGetLastError());
   ctx->stats.pairs += 1;
