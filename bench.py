@@ -548,6 +548,10 @@ def main():
     def timed_region(engine, step, steps):
         """W untimed steps, then K timed steps between barriers; kernel timing on (one launch in eight)."""
         m.set_engine(engine)
+        # Kernel timing is already on during the preheat and the warm-up: the second timed launch of
+        # a process with an RCCL communicator takes 5 ms longer than any other (a one-time effect of
+        # the timing marker, seen in a kernel trace), and that belongs to the warm-up.
+        m.set_profiling(not args.no_profile_events)
         t_heat = time.perf_counter()
         while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
             for _ in range(20 if per_step == 1 else 2):

@@ -95,6 +95,7 @@ struct sfm_hip_ctx {
   hipStream_t distance_stream = nullptr;   // all launches of the distance kernel, in order
   hipStream_t tail_streams[sfm_host::N_TAIL_STREAMS] = {};
   unsigned launches_since_timed = 0;       // profiling: distance launches since the last timed one
+  hipEvent_t previous_stop = nullptr;      // profiling: completion of the launch before one that will be timed from it
   std::map<int64_t, sfm_host::Image> images;
   std::string last_error;
   unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan

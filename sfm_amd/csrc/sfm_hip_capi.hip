@@ -112,6 +112,8 @@ int fold_timed(sfm_hip_ctx* ctx) {
   }
   ctx->timed.clear();
   ctx->launches_since_timed = 0;   // the next launch is timed again
+  if (ctx->previous_stop) ctx->event_pool.push_back(ctx->previous_stop);
+  ctx->previous_stop = nullptr;
   return SFM_HIP_OK;
 }
 
@@ -261,6 +263,7 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
     (void)hipEventDestroy(t.start);
     (void)hipEventDestroy(t.stop);
   }
+  if (ctx->previous_stop) (void)hipEventDestroy(ctx->previous_stop);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   delete ctx;
 }
@@ -546,25 +549,55 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       // The event the tail waits for rides on the kernel's own dispatch packet
       // (hipExtLaunchKernelGGL): it costs nothing, where a separate event record puts a marker
       // packet, and several microseconds, between this kernel and the next.  While profiling is
-      // on, one launch in PROFILE_EVERY also gets a start event -- such a marker packet -- and
-      // its duration goes into the statistics; the launches in between run as they always do.
+      // on, one launch in PROFILE_EVERY is timed and its duration goes into the statistics; the
+      // launches in between run as they always do.  A launch of a few pairs is timed from a start
+      // event of its own, i.e. one such marker packet.  A launch of a batch is timed from the
+      // completion of the launch before it (both events ride on dispatch packets, and launches
+      // follow each other within 30 us on their stream, against milliseconds of kernel): a marker
+      // in front of the second timed batch launch of a run of launches was seen to stretch that
+      // kernel by 5 ms (8.3 -> 13.6 ms in a kernel trace, reproducibly), which falsified both the
+      // figure and the run.  A batch launch with no launch before it to be timed from (the first
+      // after the statistics were reset) takes the marker, which is harmless there.
       void (*kernel)(const PairDev*, const BlockDev*) =
           ctx->engine == SFM_HIP_ENGINE_F16X3 ? k_distance_topk<ENGINE_F16X3> : k_distance_topk<ENGINE_F32>;
       hipEvent_t finished = L.distance_done;
       L.half_queued = true;
       TimedLaunch tl{};
-      if (ctx->profiling && ctx->launches_since_timed++ % PROFILE_EVERY == 0) {
-        tl.start = get_event(ctx);
-        tl.stop = get_event(ctx);
-        if (!tl.start || !tl.stop) {   // no events to be had: this launch runs untimed, like its neighbours
-          if (tl.start) ctx->event_pool.push_back(tl.start);
-          if (tl.stop) ctx->event_pool.push_back(tl.stop);
-          tl.start = tl.stop = nullptr;
+      const bool batch_launch = n_blocks > 4 * ctx->n_cu;
+      bool time_this = false, next_is_timed = false;
+      if (ctx->profiling) {
+        time_this = ctx->launches_since_timed % PROFILE_EVERY == 0;
+        next_is_timed = (ctx->launches_since_timed + 1) % PROFILE_EVERY == 0;
+        ctx->launches_since_timed++;
+      }
+      hipEvent_t timed_from = ctx->previous_stop;   // set by the launch before this one, if at all
+      ctx->previous_stop = nullptr;
+      bool own_marker = false;
+      if (time_this) {
+        if (batch_launch && timed_from) {
+          tl.start = timed_from;
+          timed_from = nullptr;
+          tl.stop = get_event(ctx);
+          if (!tl.stop) {
+            ctx->event_pool.push_back(tl.start);
+            tl.start = nullptr;
+          }
+        } else {
+          own_marker = true;
+          tl.start = get_event(ctx);
+          tl.stop = get_event(ctx);
+          if (!tl.start || !tl.stop) {   // no events to be had: this launch runs untimed, like its neighbours
+            if (tl.start) ctx->event_pool.push_back(tl.start);
+            if (tl.stop) ctx->event_pool.push_back(tl.stop);
+            tl.start = tl.stop = nullptr;
+          }
         }
       }
+      if (timed_from) ctx->event_pool.push_back(timed_from);   // was not needed after all
       if (tl.start) {
         tl.flop = flop;
-        hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, tl.start, tl.stop, 0, dp, db);
+        hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, own_marker ? tl.start : nullptr, tl.stop, 0, dp,
+                              db);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
           ctx->event_pool.push_back(tl.start);
@@ -574,6 +607,10 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
         ctx->timed.push_back(tl);
         finished = tl.stop;
       } else {
+        if (next_is_timed && batch_launch) {
+          hipEvent_t ev = get_event(ctx);
+          if (ev) finished = ctx->previous_stop = ev;
+        }
         hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(256), 0, ds, nullptr, finished, 0, dp, db);
         HIP_TRY(ctx, hipGetLastError());
       }
