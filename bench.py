@@ -228,12 +228,18 @@ class SetJob:
         idx = self.mine[(np.arange(PAIRS_PER_CALL) + k * PAIRS_PER_CALL) % n]
         return self.pairs[idx]
 
-    def run(self, m):
+    def run(self, m, upload_as_needed=False):
         """The whole shard through 64-pair calls, two sets of pinned outputs in turn: the GPU matches
         call b, with call b + 1 queued behind it, while the host copies the compact lists of call
-        b - 1 out.  Returns (counts, lhs, rhs)."""
+        b - 1 out.  upload_as_needed: nothing is resident at the start; an image is uploaded right
+        before the first call that names it, while the GPU works on the calls queued before (what
+        the C++ matcher class does; the shard follows a space-filling curve over the pair triangle,
+        so a call brings few new images).  Returns (counts, lhs, rhs); self.upload_seconds is the
+        time spent inside those upload calls."""
         counts = np.zeros(len(self.mine), np.int32)
         lhs_parts, rhs_parts = [], []
+        resident = set()
+        self.upload_seconds = 0.0
 
         def collect(lo, out):
             cnt, lhs, rhs, _ = out
@@ -245,6 +251,13 @@ class SetJob:
         prev = None
         for lo in range(0, len(self.mine), PAIRS_PER_CALL):
             p = self.pairs[self.mine[lo:lo + PAIRS_PER_CALL]]
+            if upload_as_needed:
+                t_up = time.perf_counter()
+                for i in np.unique(p).tolist():
+                    if i not in resident:
+                        m.upload(i, self.images[i])
+                        resident.add(i)
+                self.upload_seconds += time.perf_counter() - t_up
             # queued behind call b - 1; no distances, as the C++ matcher class calls it (a Match record has none)
             out = m.match_pairs_async(p, 0.8, True, stride=N_FEATURES, want_dist=False)
             if prev is not None:
@@ -284,18 +297,24 @@ def whole_job_leg(m, job, barrier, max_over_ranks, device, engine):
     from sfm_amd.distributed import gather_flat
     m.drop_all()
     barrier()
-    t0 = time.perf_counter()
-    job.upload(m, device)
-    m.sync()
-    barrier()
-    t_up = max_over_ranks(time.perf_counter() - t0)
+    # Host uploads ride along with the matching (an image goes up right before the first call that
+    # names it); a collective replication is a phase of its own, between barriers.
+    overlapped = job.replication != "collective"
+    t_up = 0.0
+    if not overlapped:
+        t0 = time.perf_counter()
+        job.upload(m, device)
+        m.sync()
+        barrier()
+        t_up = max_over_ranks(time.perf_counter() - t0)
     m.set_profiling(True)
     m.reset_stats()
     t0 = time.perf_counter()
-    counts, lhs, rhs = job.run(m)
+    counts, lhs, rhs = job.run(m, upload_as_needed=overlapped)
     t_local = time.perf_counter() - t0
     barrier()
     t_match = max_over_ranks(time.perf_counter() - t0)
+    t_up_inside = max_over_ranks(job.upload_seconds) if overlapped else 0.0
     st = m.stats()
     m.set_profiling(False)
     t0 = time.perf_counter()
@@ -318,7 +337,9 @@ def whole_job_leg(m, job, barrier, max_over_ranks, device, engine):
                        "%d-pair calls of sfm_hip_match_pairs" % (job.n_images, N_FEATURES, n, PAIRS_PER_CALL),
            "n_gpus": job.world, "pairs": n, "replication": job.replication,
            "images_resident_per_rank": job.images_per_rank,
-           "uploads_s": t_up, "match_s": t_match, "gather_s": t_gather,
+           "uploads": "overlapped with matching: each image right before the first call that names it (inside match_s)"
+                      if overlapped else "a phase of its own before the matching",
+           "uploads_s": t_up_inside if overlapped else t_up, "match_s": t_match, "gather_s": t_gather,
            "pairs_per_s_matching": n / t_match, "pairs_per_s_with_uploads_and_gather": n / (t_up + t_match + t_gather),
            "value": n / (t_up + t_match + t_gather), "unit": "pairs/s",
            "frac_of_fp32_mfma_peak_matching": n / t_match * flop / (job.world * PEAK_FP32_MFMA_TFLOPS * 1e12),
