@@ -227,6 +227,22 @@ def test_ragged_batch_in_one_call(matcher):
         assert_same(got, exp, "pair %s" % ((a, b),))
 
 
+def test_ragged_batch_with_first_images_of_several_sweeps(matcher):
+    """One call whose first images range from empty to several compaction sweeps (2,048 rows each):
+    the compaction's workgroups past a pair's last row must leave its count and lists alone."""
+    sizes = [5000, 100, 2049, 4096, 0, 2048]
+    base = synth.make_image_set(len(sizes), max(sizes), 0.6, seed=501)
+    imgs = [np.ascontiguousarray(base[k][:n]) for k, n in enumerate(sizes)]
+    for k, im in enumerate(imgs):
+        matcher.upload(200 + k, im)
+    pairs = [(200 + a, 200 + b) for a in range(len(sizes)) for b in range(len(sizes)) if a != b]
+    for cross in (True, False):
+        res = matcher.match_pairs(pairs, 0.8, cross)
+        for (a, b), got in zip(pairs, res):
+            exp = oracle.match_pair(imgs[a - 200], imgs[b - 200], 0.8, cross, threads=4)
+            assert_same(got, exp, "pair %s cross %s" % ((a, b), cross))
+
+
 @pytest.mark.parametrize("scale", [1.0, 37.0])
 def test_ratio_test_at_its_threshold(matcher, scale):
     """Queries whose nearest / second-nearest distance ratio straddles 0.8 within a few parts per
@@ -340,6 +356,32 @@ def test_profiling_times_one_launch_in_eight(matcher):
     assert st["distance_launches"] == 3            # launches 0, 8 and 16
     assert st["distance_ms"] > 0.0
     assert st["distance_flop"] == 3 * 2.0 * 512 * 512 * 128
+
+
+def test_profiling_of_batch_launches_matches_the_wall_clock(matcher):
+    """Launches of a batch are timed from the completion of the launch before them (no marker
+    packet): the timed launches' average must agree with the wall clock of a run of back-to-back
+    calls, none of them standing out."""
+    import time
+    A, B, _ = synth.make_pair(4096, 4096, 1000, seed=5)
+    matcher.upload(0, A)
+    matcher.upload(1, B)
+    pairs = [(0, 1)] * 32
+    for _ in range(4):
+        matcher.match_pairs_async(pairs, 0.8, True)
+    matcher.sync()
+    matcher.set_profiling(True)
+    matcher.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(25):
+        matcher.match_pairs_async(pairs, 0.8, True)
+    matcher.sync()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / 25
+    st = matcher.stats()
+    matcher.set_profiling(False)
+    assert st["distance_launches"] == 4            # launches 0, 8, 16 and 24
+    per_launch = st["distance_ms"] / st["distance_launches"]
+    assert 0.8 * wall_ms < per_launch < 1.1 * wall_ms, (per_launch, wall_ms)
 
 
 def test_nan_and_inf_in_descriptors_fall_back_to_the_exact_scan(matcher):
