@@ -66,6 +66,9 @@ void xcd_order(int nrb, int nch, int chunk_cols, int first_pos, Sink&& sink) {
       best_gr = gr;
     }
   }
+#ifdef SFM_XCD_ROW_CUTS_FROM_ENV   // diagnostic build: the cut is taken from the environment
+  if (const char* forced = getenv("SFM_XCD_ROW_CUTS")) best_gr = atoi(forced);
+#endif
   const int gr = best_gr, gc = N_XCD / gr;
   int r0[N_XCD], nr[N_XCD], c0[N_XCD];
   size_t size[N_XCD], cursor[N_XCD] = {0};
