@@ -206,12 +206,14 @@ void* sfm_hip_host_alloc(size_t bytes);
 void sfm_hip_host_free(void* p);
 
 /* Profiling: when enabled, one launch in eight of the distance/top-k kernel (the first after
- * sfm_hip_reset_stats or sfm_hip_get_stats among them) is bracketed by HIP events on the stream it
+ * sfm_hip_reset_stats or sfm_hip_get_stats among them) is timed with HIP events on the stream it
  * runs on.  Distance kernels run one after the other on a stream of their own and each batch's short
  * tail kernels on one of two other streams, so a launch never shares the chip with another launch
- * of its kind; the start event is a packet of its own in front of the kernel and costs a few
- * microseconds, which is why not every launch carries one.  sfm_hip_get_stats() waits for the
- * queued work and folds the durations into distance_ms. */
+ * of its kind.  A timed launch that is queued while the launch before it is still unfinished is
+ * timed from that launch's completion to its own (both events ride on the kernels' dispatch
+ * packets; the microseconds between two launches count in); one that finds the stream idle gets a
+ * start event of its own, a packet in front of the kernel that costs a few microseconds.
+ * sfm_hip_get_stats() waits for the queued work and folds the durations into distance_ms. */
 int sfm_hip_set_profiling(sfm_hip_ctx* ctx, int enabled);
 int sfm_hip_get_stats(sfm_hip_ctx* ctx, sfm_hip_stats* out);
 int sfm_hip_reset_stats(sfm_hip_ctx* ctx);

@@ -553,20 +553,20 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       // (hipExtLaunchKernelGGL): it costs nothing, where a separate event record puts a marker
       // packet, and several microseconds, between this kernel and the next.  While profiling is
       // on, one launch in PROFILE_EVERY is timed and its duration goes into the statistics; the
-      // launches in between run as they always do.  A launch of a few pairs is timed from a start
-      // event of its own, i.e. one such marker packet.  A launch of a batch is timed from the
-      // completion of the launch before it (both events ride on dispatch packets, and launches
-      // follow each other within 30 us on their stream, against milliseconds of kernel): a marker
-      // in front of the second timed batch launch of a run of launches was seen to stretch that
-      // kernel by 5 ms (8.3 -> 13.6 ms in a kernel trace, reproducibly), which falsified both the
-      // figure and the run.  A batch launch with no launch before it to be timed from (the first
-      // after the statistics were reset) takes the marker, which is harmless there.
+      // launches in between run as they always do.  A timed launch that is queued while the launch
+      // before it has not finished -- launches queued back to back, the case that matters -- is
+      // timed from that launch's completion to its own: both events ride on dispatch packets and
+      // nothing is added to the stream (what lies between two launches, 1-2 us for a single pair and
+      // 25-30 us of table copy for a batch, counts in).  Otherwise -- the first launch after a pause
+      // -- it gets a start event of its own, i.e. one marker packet.  Markers in front of launches
+      // in a busy stream were dropped for what they did to the run: 1.1 % of the single-pair step
+      // rate at one in eight, and the second marker-timed 64-pair launch of a run of launches took
+      // 13.6 ms instead of 8.3, reproducibly (kernel trace).
       void (*kernel)(const PairDev*, const BlockDev*) =
           ctx->engine == SFM_HIP_ENGINE_F16X3 ? k_distance_topk<ENGINE_F16X3> : k_distance_topk<ENGINE_F32>;
       hipEvent_t finished = L.distance_done;
       L.half_queued = true;
       TimedLaunch tl{};
-      const bool batch_launch = n_blocks > 4 * ctx->n_cu;
       bool time_this = false, next_is_timed = false;
       if (ctx->profiling) {
         time_this = ctx->launches_since_timed % PROFILE_EVERY == 0;
@@ -577,7 +577,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       ctx->previous_stop = nullptr;
       bool own_marker = false;
       if (time_this) {
-        if (batch_launch && timed_from) {
+        if (timed_from && hipEventQuery(timed_from) == hipErrorNotReady) {
           tl.start = timed_from;
           timed_from = nullptr;
           tl.stop = get_event(ctx);
@@ -596,6 +596,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
           }
         }
       }
+      (void)hipGetLastError();   // hipErrorNotReady is an answer, not a failure
       if (timed_from) ctx->event_pool.push_back(timed_from);   // was not needed after all
       if (tl.start) {
         tl.flop = flop;
@@ -610,7 +611,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
         ctx->timed.push_back(tl);
         finished = tl.stop;
       } else {
-        if (next_is_timed && batch_launch) {
+        if (next_is_timed) {
           hipEvent_t ev = get_event(ctx);
           if (ev) finished = ctx->previous_stop = ev;
         }
