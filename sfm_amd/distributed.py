@@ -110,10 +110,14 @@ def gather_flat(per_pair, columns, shards, rank, world, group=None, device=None,
         cnt = got[r][:len(shards[r]), -1].astype(np.int64)
         src = np.zeros(len(cnt) + 1, np.int64)
         np.cumsum(cnt, out=src[1:])
-        dst = offsets[shards[r]]
-        # pair by pair: a shard is a 2-D block of the triangle, so its pairs lie scattered over the list
-        for q in range(len(cnt)):
-            columns_all[:, dst[q]:dst[q] + cnt[q]] = per_rank[r][:, src[q]:src[q + 1]]
+        idx = np.asarray(shards[r], np.int64)
+        dst = offsets[idx]
+        # run by run: a shard is a 2-D block of the triangle, so its pairs lie scattered over the
+        # list, but neighbours in the shard are often neighbours in the list too
+        starts = np.concatenate(([0], np.nonzero(np.diff(idx) != 1)[0] + 1, [len(idx)])) if len(idx) else np.zeros(1, np.int64)
+        for a, b in zip(starts[:-1].tolist(), starts[1:].tolist()):
+            n = int(src[b] - src[a])
+            columns_all[:, dst[a]:dst[a] + n] = per_rank[r][:, src[a]:src[b]]
     return per_pair_all, offsets, [columns_all[j] for j in range(c)]
 
 
