@@ -384,6 +384,29 @@ def test_profiling_of_batch_launches_matches_the_wall_clock(matcher):
     assert 0.8 * wall_ms < per_launch < 1.1 * wall_ms, (per_launch, wall_ms)
 
 
+def test_profiling_switched_on_and_off_between_calls(matcher):
+    """Timing state (the event a timed launch is timed from) survives profiling being switched off
+    and on again and a drain in between; results are unaffected."""
+    A, B, _ = synth.make_pair(1500, 1200, 400, seed=11)
+    matcher.upload(0, A)
+    matcher.upload(1, B)
+    exp = oracle.match_pair(A, B, 0.8, True, threads=4)
+    matcher.reset_stats()
+    total = 0
+    for rounds, on in ((7, True), (5, False), (9, True), (3, False), (12, True)):
+        matcher.set_profiling(on)
+        outs = [matcher.match_pairs_async([(0, 1)], 0.8, True) for _ in range(rounds)]
+        if rounds % 2:
+            matcher.sync()
+        total += rounds
+    st = matcher.stats()
+    matcher.set_profiling(False)
+    assert st["pairs"] == total
+    assert 1 <= st["distance_launches"] <= 7 + 9 + 12
+    assert st["distance_ms"] > 0.0
+    assert_same(matcher.match_pairs([(0, 1)], 0.8, True)[0], exp, "after the switches")
+
+
 def test_nan_and_inf_in_descriptors_fall_back_to_the_exact_scan(matcher):
     """A NaN or an infinity in an image makes its norms useless for the candidate bounds: every query
     of the pair is then answered by the exact full scan, and the result is still the oracle's (a
