@@ -2,8 +2,7 @@
 # Kernel trace of the sharded bench on one rank: durations of the distance launches of the last steps and the gaps between them
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/dist_trace; rm -rf $O
 cd /tmp && export TMPDIR=/tmp
-SFM_HIP_DEBUG_TIMED=1 SFM_BENCH_BACKEND=${BACKEND:-nccl} SFM_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --gpus 1 --steps 40 --warmup 5 --set-images 60 --no-whole-job --no-replication-check $EXTRA > $O.log 2>&1 || { tail -5 $O.log; exit 1; }
-grep "timed distance" $O.log | tr "\n" " "; echo
+SFM_BENCH_BACKEND=${BACKEND:-nccl} SFM_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --gpus 1 --steps 40 --warmup 5 --set-images 60 --no-whole-job --no-replication-check $EXTRA > $O.log 2>&1 || { tail -5 $O.log; exit 1; }
 python3 - $O/*/*kernel_trace.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
