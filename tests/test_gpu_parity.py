@@ -381,7 +381,10 @@ def test_profiling_of_batch_launches_matches_the_wall_clock(matcher):
     matcher.set_profiling(False)
     assert st["distance_launches"] == 4            # launches 0, 8, 16 and 24
     per_launch = st["distance_ms"] / st["distance_launches"]
-    assert 0.8 * wall_ms < per_launch < 1.1 * wall_ms, (per_launch, wall_ms)
+    # (a launch stretched to 1.6 times its length, as a timing marker once did, would read 1.12 here;
+    # the lower bound only says that the figure is a launch's duration at all: a host that falls
+    # behind lengthens the wall clock, not the launches)
+    assert 0.5 * wall_ms < per_launch < 1.08 * wall_ms, (per_launch, wall_ms)
 
 
 def test_profiling_switched_on_and_off_between_calls(matcher):
