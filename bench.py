@@ -15,7 +15,11 @@ block's images, and a step is one 64-pair call of sfm_hip_match_pairs on the
 next pairs of the rank's shard -- the way the C++ matcher class drives the
 library.  Pairs are independent, so there is no collective on the data path and
 per-GPU work per step is fixed ("weak" scaling); value = pairs all ranks matched
-/ the slowest rank's time.  After the timed region the same ranks run the whole
+/ the slowest rank's time.  The ranks come from a launcher (torch.distributed.run
+sets WORLD_SIZE) or, when there is none, from this program itself: `python
+bench.py --gpus N` starts N rank processes and relays rank 0's line.  The line
+carries the same step measured on rank 0's GPU alone (n1_same_step_pairs_per_s)
+and the scaling efficiency against it.  After the timed region the same ranks run the whole
 job once, uploads, matching and the gather of all match lists to rank 0 timed
 separately ("whole_job"), and time the two ways of replicating a descriptor set
 ("replication").
@@ -432,6 +436,56 @@ def roofline(st, engine, traffic):
     return r
 
 
+def launch_ranks(n, script=None, argv=None):
+    """`python bench.py --gpus N` without a launcher around it: this process becomes the parent of N
+    rank processes (the environment torch.distributed.run would give them), relays what they print
+    -- rank 0 prints the JSON line -- and exits non-zero if any of them does.  It makes no GPU call
+    itself (counting devices is none) and replaces no process image: children are started with
+    subprocess before anything here could touch the GPU."""
+    import socket
+    import subprocess
+    import torch
+
+    backend = os.environ.get("SFM_BENCH_BACKEND", "nccl")
+    visible = torch.cuda.device_count()
+    if n > visible and backend != "gloo":
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) are visible; one rank per GPU over RCCL needs %d "
+                         "(SFM_BENCH_BACKEND=gloo lets ranks share GPUs for a rehearsal)\n" % (n, visible, n))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SFM_BENCH_LAUNCHED_BY="bench.py")
+        # rank 0 owns this process's stdout (the one JSON line); whatever another rank prints is commentary
+        children.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)]
+                                         + (sys.argv[1:] if argv is None else list(argv)), env=env,
+                                         stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    kill_at = None
+    pending = dict(enumerate(children))
+    while pending:
+        for r, c in list(pending.items()):
+            code = c.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:
+                rc = code if 0 < code < 256 else 1
+                sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                for o in pending.values():     # exactly the processes started above
+                    o.terminate()
+                kill_at = time.monotonic() + 15.0
+        if kill_at is not None and time.monotonic() > kill_at:
+            for o in pending.values():
+                o.kill()
+            kill_at = None
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,9 +527,18 @@ def main():
                     help="do not bracket the distance kernel with HIP events in the timed region")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        # a launcher's world size and --gpus must say the same thing: a line whose n_gpus differs from
+        # what was asked for is worse than no line
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # SFM_BENCH_FORCE_DIST=1 takes the multi-rank code path (sharded job, RCCL group, barriers, max
@@ -566,8 +629,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed_region(engine, step, steps):
-        """W untimed steps, then K timed steps between barriers; kernel timing on (one launch in eight)."""
+    def timed_region(engine, step, steps, alone=False):
+        """W untimed steps, then K timed steps between barriers; kernel timing on (one launch in eight).
+        alone: this rank only, no barrier with the others (they are parked at one)."""
+        dist_on_here = dist_on and not alone
         m.set_engine(engine)
         # Kernel timing is already on during the preheat and the warm-up: the second timed launch of
         # a process with an RCCL communicator takes 5 ms longer than any other (a one-time effect of
@@ -580,9 +645,9 @@ def main():
             m.sync()
         # The W warm-up steps are still running while the ranks meet at the barrier (with a few more
         # behind them to cover it): a barrier on an idle GPU lets its clocks drop again.
-        for _ in range(args.warmup + (40 if dist_on and per_step == 1 else 0)):
+        for _ in range(args.warmup + (40 if dist_on_here and per_step == 1 else 0)):
             step()
-        if dist_on:
+        if dist_on_here:
             dist.barrier()
         m.sync()
         m.set_profiling(not args.no_profile_events)
@@ -592,11 +657,24 @@ def main():
         for _ in range(steps):
             out = step()
         m.sync()
-        barrier()
+        if dist_on_here:
+            dist.barrier()
+        torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         st = m.stats()
         m.set_profiling(False)
         return out, elapsed, st
+
+    # The like-for-like denominator of a scaling figure, measured in this run: rank 0 does the same
+    # steps (64-pair calls on its own shard) while every other rank waits at a barrier, its GPU idle.
+    solo = None
+    if dist_on:
+        if rank == 0:
+            _, solo_elapsed, solo_st = timed_region(args.engine, step, args.steps, alone=True)
+            solo = {"value": args.steps * per_step / solo_elapsed, "ms_per_step": solo_elapsed / args.steps * 1e3,
+                    "roofline": roofline(solo_st, args.engine, None)}
+            step_no[0] = 0
+        barrier()
 
     out, elapsed, st = timed_region(args.engine, step, args.steps)
     out = tuple(a.copy() for a in out)    # the pinned buffers are the binding's and go when the call shape changes
@@ -628,6 +706,9 @@ def main():
         rates = torch.zeros(world, dtype=torch.float64, device=coll_device)
         rates[rank] = rate
         dist.all_reduce(rates)
+        ordinals = torch.zeros(world, dtype=torch.float64, device=coll_device)
+        ordinals[rank] = device.index
+        dist.all_reduce(ordinals)
         replication = None if args.no_replication_check else replication_check(m, rank, world, coll_device, barrier)
         whole = None if args.no_whole_job else whole_job_leg(m, job, barrier, max_over_ranks, coll_device, args.engine)
         if rank == 0:
@@ -638,6 +719,16 @@ def main():
                 "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                # what actually ran: ranks of the process group, its backend ("nccl" is RCCL), each rank's device
+                "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                "device_ordinal_per_rank": [int(x) for x in ordinals.tolist()],
+                "launched_by": os.environ.get("SFM_BENCH_LAUNCHED_BY", "an outside launcher (torch.distributed.run)"),
+                # the same step on rank 0's GPU alone, the other ranks waiting at a barrier: the
+                # denominator a scaling figure of THIS line needs (not the N = 1 line's headline value,
+                # which is one pair per call)
+                "n1_same_step_pairs_per_s": solo["value"], "n1_same_step_ms_per_step": solo["ms_per_step"],
+                "n1_same_step_roofline": solo["roofline"],
+                "scaling_efficiency": value / (world * solo["value"]),
                 "config": {"workload": "exhaustive matching of %d synthetic images x %d features (%d pairs, BASELINE.json "
                                        "configs[%s]%s), ratio 0.8 + cross-check, pair list cut into %d shards of equal cost "
                                        "(2-D blocks of the pair triangle); a step = one %d-pair call of sfm_hip_match_pairs "
@@ -689,6 +780,8 @@ def main():
             "pairs_per_s_this_gpu_without_kernel_timing": free_rate,
             "roofline": roofline(st, args.engine, traffic),
         }
+        if traffic is not None:
+            line["roofline"]["traffic_source"] = "profiles/distance_kernel_traffic.json (separate counter run)"
         if not args.no_other_engine:
             # the library's other distance engine on the same steps (its own timed region)
             other = "f16x3" if args.engine == "f32" else "f32"
@@ -705,6 +798,8 @@ def main():
             m.set_engine(args.engine)
         if not args.no_batched and per_step == 1:
             line["batched"] = batched_leg(m, args.engine)
+            # the step of the N > 1 lines (64-pair calls) on this one GPU: what their value divides by
+            line["value_same_step_as_multi_gpu"] = line["batched"]["value"]
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, B, got)
         if not args.no_batched and per_step == 1:
