@@ -137,21 +137,24 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
                         int cross_check, int32_t* out_counts, int32_t* out_lhs_idx,
                         int32_t* out_rhs_idx, float* out_dist, int64_t out_stride);
 
-/* The same match for ONE pair, for callers that cannot allocate: code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (whose
- * matcher allocates per task, brute_force_matcher.cc:47-52).  The call allocates and frees nothing,
- * on the device or through the HIP runtime: its work space (candidate lists, per-query results, the
- * table of workgroups) is a fixed array of 8 MiB that is part of the library's GPU code, one copy per
- * GPU, held until the process ends.  Limits and rules:
+/* The same match for ONE pair, for callers that cannot allocate: tight serving loops with a fixed
+ * memory budget, harnesses that forbid hipMalloc, programs that must not disturb a HIP graph capture
+ * going on elsewhere in the process with an allocation.  (The call itself runs on the context's own
+ * streams and takes no stream argument: it is not something to record INTO a caller's graph.)  It
+ * has no counterpart in the reference (whose matcher allocates per task,
+ * brute_force_matcher.cc:47-52).  The call allocates and frees nothing, on the device, through the
+ * HIP runtime or on the host heap: its work space (candidate lists, per-query results, the table of
+ * workgroups) is a fixed array of 8 MiB that is part of the library's GPU code, one copy per GPU,
+ * held until the process ends; its streams and events were made with the context.  Limits and rules:
  *   - both images hold at most SFM_HIP_NOALLOC_MAX_ROWS descriptors; larger ones are refused
  *     (SFM_HIP_ERR_INVALID), use sfm_hip_match_pairs for them;
  *   - out_lhs_idx / out_rhs_idx / out_dist have room for as many entries as the first image has
  *     descriptors, out_count for one; the kernels write them directly, so they must be pinned host
  *     memory (sfm_hip_host_alloc) or device memory; out_dist may be NULL;
  *   - the results are those of sfm_hip_match_pairs for the same pair, bit for bit;
- *   - asynchronous like sfm_hip_match_pairs (outputs are valid after sfm_hip_sync); calls on one
- *     context run one after the other, in call order, also relative to sfm_hip_match_pairs calls that
- *     write the same outputs;
+ *   - asynchronous like sfm_hip_match_pairs (outputs are valid after sfm_hip_sync, or after
+ *     sfm_hip_wait_outputs on one of them); calls on one context run one after the other, in call
+ *     order, also relative to earlier and later sfm_hip_match_pairs calls that write the same outputs;
  *   - every call on a GPU uses that GPU's one array: calls through two contexts of the same GPU
  *     that overlap in time race (as do two host threads driving one context, which no entry point
  *     allows).  Calls on different GPUs, and in different processes, do not interfere. */
@@ -198,7 +201,8 @@ int sfm_hip_sync(sfm_hip_ctx* ctx);
  * other memory, are still running.  This is the reference's future.get() for ONE pair's task
  * (brute_force_matcher.cc:67-68), where sfm_hip_sync is the join of all of them: a host loop can
  * keep a call queued behind the running one and still consume results call by call.  Calls of
- * sfm_hip_match_pairs and sfm_hip_cascade_match_pairs are covered. */
+ * sfm_hip_match_pairs, sfm_hip_match_pair_noalloc and sfm_hip_cascade_match_pairs are covered; the
+ * wait may last until a later call on the same internal stream has finished too, never less. */
 int sfm_hip_wait_outputs(sfm_hip_ctx* ctx, const void* out, size_t bytes);
 
 /* Pinned host memory for the output buffers. */

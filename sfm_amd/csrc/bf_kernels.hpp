@@ -48,6 +48,12 @@ constexpr int COL_IDX_BITS = 8;      // column lists: low bits = row inside the 
 constexpr uint32_t COL_LOW = (1u << COL_IDX_BITS) - 1u;
 constexpr uint32_t COL_MASK = 0x7FFFFFFFu & ~COL_LOW;
 constexpr float PAD_NORM = 1e30f;    // squared norm given to padding rows: never a near neighbour
+// Keys (and with them every bound the re-rank derives from keys) mean something only while all real
+// rows of both images have squared norms below this: from PAD_NORM on the distance kernel gives a
+// row the key of a padding row.  The reference has no such limit (src/metric.hpp:15-22 is plain
+// fp32 arithmetic up to overflow), so a pair with a larger norm on either side is answered by the
+// exact full scan, query by query.
+constexpr float NORM_LIMIT = 1e29f;
 constexpr int NCAND = 4;             // candidates re-ranked exactly per query
 constexpr int ROWPART_FIELDS = 2 * NCAND + 1;  // keys, column indices, bound key
 
@@ -159,7 +165,10 @@ __global__ __launch_bounds__(256) void k_norms(const float* __restrict__ x, floa
       m = fmaxf(m, __shfl_xor(m, o));
     }
     if (l == 0) xn[row] = s;
-    big = fmaxf(big, s);
+    // A row whose squared norm is not an ordinary number below NORM_LIMIT (NaN, infinity, overflow, or
+    // so large that it is no longer told apart from a padding row) makes the image's largest norm
+    // infinite: k_rerank then proves nothing from keys for any pair of this image.
+    big = s < NORM_LIMIT ? fmaxf(big, s) : __builtin_inff();
     mag = fmaxf(mag, m);
   }
   if (l == 0) {
@@ -1152,6 +1161,10 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
   const float* qn_arr = dir == 0 ? P.xn : P.yn;
   const float my_qn = (tid < RR_QUERIES && q0 + tid < nq) ? qn_arr[q0 + tid] : 0.0f;
   const float other_max = (dir == 0 ? P.yn : P.xn)[dir == 0 ? P.nb_pad : P.na_pad];
+  const float own_max = (dir == 0 ? P.xn : P.yn)[dir == 0 ? P.na_pad : P.nb_pad];
+  // false: keys of this pair prove nothing (NaN compares false as well) -- no decision from keys
+  // below, and every query fails the completeness check and takes the exact scan of step D
+  const bool provable = other_max < NORM_LIMIT && own_max < NORM_LIMIT;
 
   // ---- A
   // First the three smallest keys of the query alone, values only (three v_med3/v_min per key): they
@@ -1231,8 +1244,8 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
     // The four lanes hold the same keys now (equal keys may have left different columns in `first`:
     // a query with equal smallest keys is never accepted from the keys alone).  One lane decides.
     int md = RR_FULL;
-    if (sub == 0 && q < nq && no >= NCAND && lbound != SENT && a2 != SENT && (a2 & 0x7F800000u) != 0x7F800000u &&
-        ratio > 0.0 && ratio <= 1.0) {
+    if (sub == 0 && provable && q < nq && no >= NCAND && lbound != SENT && a2 != SENT &&
+        (a2 & 0x7F800000u) != 0x7F800000u && ratio > 0.0 && ratio <= 1.0) {
       // Every column's reference sum lies in [lower bound, upper bound] of its key; the columns
       // outside the lists lie above the lower bound of the smallest list bound, and every column but
       // the two smallest keys' above the lower bound of the third smallest key:
@@ -1369,7 +1382,8 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
       //       sqrt(hi_0) < ratio * sqrt(min(lo_1, lx))   =>  candidate 0 is the nearest and passes.
       // Square roots are taken of floats rounded outwards (sqrtf is monotone), in double as the rule.
       int md = RR_FULL;
-      if (q < nq && c0 != SENT && c1 != SENT && c2 != SENT && c3 != SENT && bound != SENT && ratio > 0.0 && ratio <= 1.0) {
+      if (provable && q < nq && c0 != SENT && c1 != SENT && c2 != SENT && c3 != SENT && bound != SENT && ratio > 0.0 &&
+          ratio <= 1.0) {
         const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
         const float nqv = qn_early;
         double lo0, lo1, hi0, hi1, lx;
@@ -1527,8 +1541,8 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
       }
     }
     const uint32_t bound = bnd[tid];
-    bool safe = no <= NCAND || bound == SENT;
-    if (!safe) {
+    bool safe = provable && (no <= NCAND || bound == SENT);
+    if (provable && !safe) {
       const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
       if (engine == ENGINE_F32) {
         safe = (double)t.r2 <= excluded_lower_bound(bound, mask, my_qn, other_max);

@@ -70,16 +70,26 @@ struct Lane {
   hipEvent_t distance_done = nullptr;   // rides on the lane's latest distance kernel
   hipEvent_t tail_done = nullptr;       // recorded after the lane's latest tail
   bool tail_pending = false;            // tail_done was recorded and not waited for yet
-  // host memory the lane's latest tail writes (counts, lhs, rhs, distances): a later batch on another
-  // lane that writes any of it again waits for this tail, so that results land in call order
-  // (the cascade-hash path has a fifth array, the default-record counts)
-  const char* out_lo[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  const char* out_hi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // Host memory written by the lane's batches whose completion the host has not seen yet (counts, lhs,
+  // rhs, distances; the cascade-hash path has a fifth array, the default-record counts).  All of a
+  // lane's batches run on one stream, so the latest tail_done covers every one of them.  A later
+  // batch on another lane that writes any of this memory again waits for that event, so that results
+  // land in call order; sfm_hip_wait_outputs waits for it on the host.  A brute-force lane holds one
+  // batch's ranges at most (it is taken again only after its tail has finished); a cascade-hash lane
+  // is taken again without a host wait and accumulates the ranges of every batch since the last one.
+  // Fixed capacity, no heap: when it is full the host waits for the lane and starts over.
+  static constexpr int MAX_OUT_RANGES = 40;
+  const char* out_lo[MAX_OUT_RANGES];
+  const char* out_hi[MAX_OUT_RANGES];
+  int n_out_ranges = 0;
   bool half_queued = false;             // a distance kernel was queued and the call failed before its tail was
 };
 
 constexpr int N_LANES = 4;
 constexpr int N_CASCADE_LANES = 2;
+// lanes[NOALLOC_LANE] is no work space at all: it stands for the calls of sfm_hip_match_pair_noalloc,
+// which run on the distance stream, so that the ordering and waiting below see their outputs too
+constexpr int NOALLOC_LANE = N_LANES;
 // A process has four hardware queues (GPU_MAX_HW_QUEUES) and streams beyond that share them, in
 // order: a tail stream on the distance stream's hardware queue would put its kernels between two
 // distance kernels again.  Distance stream + upload stream + two tail streams = four.
@@ -89,13 +99,14 @@ constexpr int N_TAIL_STREAMS = 2;
 
 struct sfm_hip_ctx {
   int device = 0;
-  sfm_host::Lane lanes[sfm_host::N_LANES];
+  sfm_host::Lane lanes[sfm_host::N_LANES + 1];
   int next_lane = 0;
   int next_cascade_lane = 0;
   hipStream_t distance_stream = nullptr;   // all launches of the distance kernel, in order
   hipStream_t tail_streams[sfm_host::N_TAIL_STREAMS] = {};
   unsigned launches_since_timed = 0;       // profiling: distance launches since the last timed one
   hipEvent_t previous_stop = nullptr;      // profiling: completion of the launch before one that will be timed from it
+  bool previous_stop_stale = false;        // ... and something other than the next launch was queued behind it since
   std::map<int64_t, sfm_host::Image> images;
   std::string last_error;
   unsigned long long* rescanned_dev = nullptr;  // queries answered by the exact full scan
@@ -145,11 +156,23 @@ inline int fail(sfm_hip_ctx* ctx, int code, const std::string& msg) {
     }                                                                                      \
   } while (0)
 
+// The host has seen the lane's latest tail finish: nothing of it is pending any more.
+inline void lane_finished(Lane& l) {
+  l.tail_pending = false;
+  l.n_out_ranges = 0;
+}
+
+inline bool lane_writes(const Lane& l, const char* lo, const char* hi) {
+  for (int b = 0; b < l.n_out_ranges; b++)
+    if (lo < l.out_hi[b] && l.out_lo[b] < hi) return true;
+  return false;
+}
+
 inline int sync_all(sfm_hip_ctx* ctx) {
   if (ctx->distance_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->distance_stream));
   for (hipStream_t t : ctx->tail_streams)
     if (t) HIP_TRY(ctx, hipStreamSynchronize(t));
-  for (Lane& l : ctx->lanes) l.tail_pending = false;
+  for (Lane& l : ctx->lanes) lane_finished(l);
   for (void* p : ctx->retired) (void)hipFree(p);   // work-space buffers replaced by larger ones since the last drain
   ctx->retired.clear();
   return SFM_HIP_OK;
@@ -214,21 +237,32 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // A caller may hand the same output memory to consecutive calls (two sets of buffers used in turn,
 // say).  Batches of different lanes run on different streams and are not ordered among themselves,
 // so before lane L's batch writes the ranges [lo[a], hi[a]) its stream waits for every pending
-// batch of another lane that writes memory overlapping them; then the ranges become L's.
+// batch of another lane that writes memory overlapping them; then the ranges are added to L's (a
+// lane whose earlier batches are known to have finished starts from none: lane_finished).
 inline int order_outputs(sfm_hip_ctx* ctx, Lane& L, hipStream_t st, const char* const (&lo)[5], const char* const (&hi)[5]) {
   for (Lane& other : ctx->lanes) {
     if (&other == &L || !other.tail_pending) continue;
     bool overlap = false;
-    for (int a = 0; a < 5 && !overlap; a++)
-      for (int b = 0; b < 5 && !overlap; b++)
-        overlap = lo[a] && other.out_lo[b] && lo[a] < other.out_hi[b] && other.out_lo[b] < hi[a];
+    for (int a = 0; a < 5 && !overlap; a++) overlap = lo[a] && lane_writes(other, lo[a], hi[a]);
 #ifndef SFM_ABLATE_OUTPUT_ORDER   // diagnostic build: shows that the test of this ordering can fail
     if (overlap) HIP_TRY(ctx, hipStreamWaitEvent(st, other.tail_done, 0));
 #endif
   }
+  if (!L.tail_pending) L.n_out_ranges = 0;
   for (int a = 0; a < 5; a++) {
-    L.out_lo[a] = lo[a];
-    L.out_hi[a] = hi[a];
+    if (!lo[a]) continue;
+    bool known = false;   // the same buffers handed over again and again take one slot
+    for (int b = 0; b < L.n_out_ranges && !known; b++) known = L.out_lo[b] == lo[a] && L.out_hi[b] == hi[a];
+    if (known) continue;
+    if (L.n_out_ranges == Lane::MAX_OUT_RANGES) {
+      // more distinct output buffers in flight on this lane than it can remember: let the lane's
+      // earlier batches finish (they run on st or, for the noalloc lane, the distance stream)
+      HIP_TRY(ctx, hipEventSynchronize(L.tail_done));
+      L.n_out_ranges = 0;
+    }
+    L.out_lo[L.n_out_ranges] = lo[a];
+    L.out_hi[L.n_out_ranges] = hi[a];
+    L.n_out_ranges++;
   }
   return SFM_HIP_OK;
 }

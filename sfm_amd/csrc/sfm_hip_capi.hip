@@ -411,7 +411,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     // the lane's work space is free once its previous tail has run
     if (L.tail_pending) {
       HIP_TRY(ctx, hipEventSynchronize(L.tail_done));
-      L.tail_pending = false;
+      lane_finished(L);
     }
     if (L.half_queued) {   // an earlier call failed between this lane's distance kernel and its tail
       if (int rc_sync = sync_all(ctx)) return rc_sync;
@@ -575,9 +575,11 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
       }
       hipEvent_t timed_from = ctx->previous_stop;   // set by the launch before this one, if at all
       ctx->previous_stop = nullptr;
+      const bool stale = ctx->previous_stop_stale;  // other kernels were queued on this stream since
+      ctx->previous_stop_stale = false;
       bool own_marker = false;
       if (time_this) {
-        if (timed_from && hipEventQuery(timed_from) == hipErrorNotReady) {
+        if (timed_from && !stale && hipEventQuery(timed_from) == hipErrorNotReady) {
           tl.start = timed_from;
           timed_from = nullptr;
           tl.stop = get_event(ctx);
@@ -771,8 +773,19 @@ int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t se
   // and must not overlap.  Tails of earlier sfm_hip_match_pairs calls run on other streams; this
   // call's results must land after theirs.
   hipStream_t ds = ctx->distance_stream;
+  Lane& NL = ctx->lanes[NOALLOC_LANE];
   for (Lane& other : ctx->lanes)
-    if (other.tail_pending) HIP_TRY(ctx, hipStreamWaitEvent(ds, other.tail_done, 0));
+    if (&other != &NL && other.tail_pending) HIP_TRY(ctx, hipStreamWaitEvent(ds, other.tail_done, 0));
+  {
+    // what this call writes, for later calls that write the same memory from another stream and for
+    // sfm_hip_wait_outputs (fixed-size bookkeeping in the context: nothing is allocated)
+    const size_t n_first = (size_t)pl.X->n;
+    const char* const lo[5] = {(const char*)out_count, (const char*)out_lhs_idx, (const char*)out_rhs_idx,
+                               (const char*)out_dist, nullptr};
+    const char* const hi[5] = {lo[0] + sizeof(int32_t), lo[1] + n_first * 4, lo[2] + n_first * 4,
+                               lo[3] ? lo[3] + n_first * 4 : nullptr, nullptr};
+    if (int rc = order_outputs(ctx, NL, ds, lo, hi)) return rc;
+  }
   const int eng = ctx->engine == SFM_HIP_ENGINE_F16X3 ? ENGINE_F16X3 : ENGINE_F32;
   hipLaunchKernelGGL(k_noalloc_tables, dim3((unsigned)std::max(1, (n_blocks + 255) / 256)), dim3(256), 0, ds, d, order,
                      n_blocks, eng, d_pair, d_blocks);
@@ -803,6 +816,11 @@ int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t se
                      (const PairDev*)d_pair, cross_check ? 1 : 0, k_count,
                      k_lhs, k_rhs, k_dist ? k_dist : d_dist, (int64_t)SFM_HIP_NOALLOC_MAX_ROWS);
   HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(NL.tail_done, ds));   // an event made with the context
+  NL.tail_pending = true;
+  // A distance launch that would be timed "from the completion of the launch before it" would now
+  // count this call's kernels in: such a launch takes a start marker of its own instead.
+  ctx->previous_stop_stale = true;
   ctx->stats.pairs += 1;
   ctx->stats.queries += (uint64_t)pl.X->n + (uint64_t)pl.Y->n;
   return SFM_HIP_OK;
@@ -820,15 +838,14 @@ int sfm_hip_wait_outputs(sfm_hip_ctx* ctx, const void* out, size_t bytes) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const char* lo = (const char*)out;
   const char* hi = lo + bytes;
-  // An unfinished batch is always the latest of its lane (a lane is taken again only after its
-  // previous batch has finished), and the lane remembers what that batch writes.
+  // A lane remembers what its batches write until the host has seen them finish, and its latest
+  // tail_done covers all of them (one stream per lane).  Waiting for a lane's latest batch can mean
+  // waiting for a later call than the one asked about (a cascade-hash lane is taken again without a
+  // host wait): never for less.
   for (Lane& L : ctx->lanes) {
-    if (!L.tail_pending) continue;
-    bool overlap = false;
-    for (int a = 0; a < 5 && !overlap; a++) overlap = L.out_lo[a] && lo < L.out_hi[a] && L.out_lo[a] < hi;
-    if (!overlap) continue;
+    if (!L.tail_pending || !lane_writes(L, lo, hi)) continue;
     HIP_TRY(ctx, hipEventSynchronize(L.tail_done));
-    L.tail_pending = false;
+    lane_finished(L);
   }
   return SFM_HIP_OK;
 }

@@ -384,10 +384,9 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
         t0 = t1 = nullptr;
       }
     }
-    // results land in call order even when calls share output memory (order_outputs, ctx.hpp)
-    if (L.tail_pending) {   // this lane's previous batch: same stream, already ordered
-      L.tail_pending = false;
-    }
+    // Results land in call order even when calls share output memory (order_outputs, ctx.hpp).  This
+    // lane's earlier batches run on the same stream and need no ordering; they may still be
+    // unfinished, so what they write stays on the lane's record beside this batch's ranges.
     {
       const char* const lo[5] = {(const char*)(out_counts + done), (const char*)(out_lhs_idx + o), (const char*)(out_rhs_idx + o),
                                  out_dist ? (const char*)(out_dist + o) : nullptr, (const char*)(out_defaults + done)};

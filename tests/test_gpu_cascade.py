@@ -302,3 +302,62 @@ def test_calls_in_flight_that_reuse_output_buffers_land_in_call_order(matcher):
             for b in bufs:
                 b.free()
         matcher.drop_all()
+
+
+def test_wait_outputs_covers_an_earlier_multi_batch_call(matcher):
+    """sfm_hip_wait_outputs on a cascade-hash call whose lanes have been taken again since: call 1
+    needs two batches (1,128 pairs, one batch on each of the two lanes), call 2 is queued behind it
+    into a second set of buffers and takes both lanes again without a host wait.  Waiting for call
+    1's counts must still wait for call 1 -- its results are read right afterwards, with call 2
+    possibly still running."""
+    from sfm_amd.binding import _Pinned
+    lib = sfm_amd.library()
+    imgs = synth.make_repetitive_set(48, 2048, 0.6, 2, seed=41, sigma=0.002)
+    images = {i: d[: 2048 - 7 * (i % 5)] for i, d in enumerate(imgs)}
+    ids = sorted(images)
+    pairs = [(a, b) for x, a in enumerate(ids) for b in ids[x + 1:]]
+    assert len(pairs) == 1128                      # more than one batch of 1,024
+    _upload(matcher, images)
+    mean = matcher.cascade_prepare(pairs)
+    p1 = np.ascontiguousarray(pairs, np.int64)
+    p2 = np.ascontiguousarray(pairs[::-1], np.int64)          # call 2: the same pairs in another order
+    stride, n = 2048, len(pairs)
+    sets = [[_Pinned(lib, s, t) for s, t in (((n,), np.int32), ((n,), np.int32), ((n, stride), np.int32),
+                                             ((n, stride), np.int32), ((n, stride), np.float32))] for _ in range(2)]
+    try:
+        for rep in range(3):
+            for bufs in sets:
+                bufs[0].array[:] = -7
+                bufs[1].array[:] = -7
+            for p, bufs in ((p1, sets[0]), (p2, sets[1])):
+                rc = lib.sfm_hip_cascade_match_pairs(matcher._h, p.ctypes.data, n, 1, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr,
+                                                     bufs[3].ptr, bufs[4].ptr, stride)
+                assert rc == 0, lib.sfm_hip_last_error(matcher._h)
+            matcher.wait_outputs(sets[0][1].array)
+            dfl, cnt = sets[0][0].array.copy(), sets[0][1].array.copy()        # call 1's, as they are NOW
+            lhs_now = {k: sets[0][2].array[k, :max(int(cnt[k]), 0)].tolist() for k in (0, 500, 1023, 1024, 1127)}
+            assert cnt.min() >= 0 and dfl.min() >= 0, "call 1 had not finished when sfm_hip_wait_outputs returned"
+            if rep == 0:
+                total = 0
+                for k in list(range(0, n, 37)) + list(range(1024, n, 9)):
+                    a, b = pairs[k]
+                    end, el, er, ed = cascade.match_pair(images[a], images[b], mean, True)
+                    c = int(cnt[k])
+                    assert (int(dfl[k]), sets[0][2].array[k, :c].tolist(), sets[0][3].array[k, :c].tolist()) == \
+                        (end, el.tolist(), er.tolist()), (a, b)
+                    assert sets[0][4].array[k, :c].view(np.uint32).tolist() == ed.view(np.uint32).tolist()
+                    total += c
+                assert total > 500
+                first = (dfl, cnt, lhs_now)
+            else:     # later rounds: the same answer, read at the same moment
+                assert np.array_equal(first[0], dfl) and np.array_equal(first[1], cnt) and first[2] == lhs_now
+            matcher.sync()
+            # call 2 wrote the same pairs in reverse order into the other set
+            assert np.array_equal(sets[1][1].array[::-1], cnt) and np.array_equal(sets[1][0].array[::-1], dfl)
+        assert matcher.cascade_stats()["workspace_dirty_words"] == 0
+    finally:
+        matcher.sync()
+        for bufs in sets:
+            for b in bufs:
+                b.free()
+        matcher.drop_all()

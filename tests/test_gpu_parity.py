@@ -154,14 +154,43 @@ def test_unknown_engine_is_rejected(matcher):
     assert b"unknown engine" in lib.sfm_hip_last_error(matcher._h)
 
 
-@pytest.mark.parametrize("scale", [1e-6, 1.0 / 512.0, 300.0, 6e4, 1e7])
+@pytest.mark.parametrize("scale", [1e-6, 1.0 / 512.0, 300.0, 6e4, 1e7, 1e15, 3e17])
 def test_descriptor_scale_does_not_change_matches(matcher, scale):
     """The split-fp16 engine rescales every image by a power of two before splitting; values far
-    outside the fp16 range (or far below it) must give the reference's matches all the same."""
+    outside the fp16 range (or far below it) must give the reference's matches all the same.  At
+    1e15 and 3e17 the squared norms (1e30, 9e34) are beyond what the candidate keys can express: the
+    reference's arithmetic (src/metric.hpp:15-22) is still finite there, and so must the answer be."""
     A, B, _ = synth.make_pair(700, 900, 300, seed=77)
     A = (A * np.float32(scale)).astype(np.float32)
     B = (B * np.float32(scale)).astype(np.float32)
-    check_pair(matcher, A, B, True)
+    matcher.reset_stats()
+    l, _, _ = check_pair(matcher, A, B, True)
+    assert len(l) >= 290                      # the planted correspondences survive at every scale
+    if scale >= 1e15:                         # ... by the exact scan, not by luck
+        assert matcher.stats()["rescanned_queries"] >= 700 + 900
+
+
+@pytest.mark.parametrize("side", ["first", "second", "both"])
+def test_a_few_rows_with_huge_norms(matcher, side):
+    """Rows whose squared norm lies between 1e29 and the fp32 maximum, among ordinary rows, on either
+    side of the pair: to the reference they are ordinary descriptors with finite distances (and near
+    each other they match); the distance kernel cannot tell them from padding rows, so the pair has
+    to be answered exactly."""
+    A, B, _ = synth.make_pair(600, 800, 250, seed=81)
+    A, B = A.copy(), B.copy()
+    rng = np.random.default_rng(3)
+    big = (rng.random((6, 128), dtype=np.float32) * np.float32(2e15)).astype(np.float32)
+    near = (big * (np.float32(1) + rng.normal(0, 1e-4, big.shape).astype(np.float32))).astype(np.float32)
+    if side in ("first", "both"):
+        A[[0, 17, 100, 256, 400, 599]] = big
+    if side in ("second", "both"):
+        B[[3, 64, 255, 256, 511, 799]] = near if side == "both" else big
+    matcher.reset_stats()
+    for cross in (False, True):
+        l, r, _ = check_pair(matcher, A, B, cross)
+    if side == "both":
+        assert {(0, 3), (17, 64), (599, 799)} <= set(zip(l.tolist(), r.tolist()))
+    assert matcher.stats()["rescanned_queries"] >= 600
 
 
 def test_images_of_very_different_scale(matcher):

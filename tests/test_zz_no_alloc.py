@@ -84,6 +84,44 @@ def test_two_calls_in_a_row_second_smaller(matcher):
             b.free()
 
 
+def test_calls_allocate_nothing_and_are_seen_by_wait_outputs(matcher):
+    """Free device memory is the same after a run of calls as before it (the work space is part of the
+    code object, every stream and event was made with the context), and sfm_hip_wait_outputs on a
+    call's count waits for that call."""
+    import torch
+    m = matcher
+    bufs = [m.pinned((1,), np.int32), m.pinned((MAX_ROWS,), np.int32), m.pinned((MAX_ROWS,), np.int32),
+            m.pinned((MAX_ROWS,), np.float32)]
+    try:
+        A, B, _ = synth.make_pair(4096, 5000, 2000, seed=35)
+        m.upload(630, A)
+        m.upload(631, B)
+        (el, er, ed), = m.match_pairs([(630, 631)], 0.8, True)
+        m.match_pair_noalloc_async(630, 631, 0.8, True, *bufs)     # first use of everything involved
+        m.sync()
+        torch.cuda.mem_get_info(0)                                 # whatever torch sets up on first use
+        free_before = torch.cuda.mem_get_info(0)[0]
+        for k in range(12):
+            bufs[0].array[0] = -7
+            m.match_pair_noalloc_async(630, 631, 0.8, k % 2 == 0, *bufs)
+            if k % 4 == 0:
+                m.wait_outputs(bufs[0].array)
+                assert int(bufs[0].array[0]) == len(el)            # k even: cross-check on
+        m.sync()
+        assert torch.cuda.mem_get_info(0)[0] == free_before
+        m.match_pair_noalloc_async(630, 631, 0.8, True, *bufs)
+        m.wait_outputs(bufs[0].array)
+        c = int(bufs[0].array[0])
+        assert bufs[1].array[:c].tolist() == el.tolist() and bufs[2].array[:c].tolist() == er.tolist()
+        assert bufs[3].array[:c].view(np.uint32).tolist() == ed.view(np.uint32).tolist()
+    finally:
+        m.sync()
+        m.drop(630)
+        m.drop(631)
+        for b in bufs:
+            b.free()
+
+
 def test_empty_image_and_no_distances(matcher):
     m = matcher
     bufs = [m.pinned((1,), np.int32), m.pinned((MAX_ROWS,), np.int32), m.pinned((MAX_ROWS,), np.int32)]
