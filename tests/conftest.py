@@ -19,6 +19,12 @@ def kat_cases():
         return json.load(f)["cases"]
 
 
+def kat_derived_cases():
+    """Cases worked out by hand from the reference's text (NOT outputs of the reference)."""
+    with open(os.path.join(ROOT, "tests", "golden", "kat_derived.json")) as f:
+        return json.load(f)["cases"]
+
+
 def kat_descriptors(rows):
     a = np.zeros((len(rows), 128), np.float32)
     for i, r in enumerate(rows):
