@@ -1,6 +1,7 @@
 #include "hip_brute_force_matcher.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -24,7 +25,18 @@ struct PairJob {
   const Descriptors* second;
   const std::vector<KeyPoint>* kl;
   const std::vector<KeyPoint>* kr;
-  Matches* out;
+};
+
+// What the helper threads did, summed over all of them (each adds its own share once per batch).
+struct HostWork {
+  std::mutex mu;
+  HipBruteForceMatcher::HostStats total;
+  void add(uint64_t pairs, uint64_t records, double seconds) {
+    std::lock_guard<std::mutex> lock(mu);
+    total.pairs += pairs;
+    total.records += records;
+    total.materialise_thread_seconds += seconds;
+  }
 };
 
 struct Progress {
@@ -47,8 +59,8 @@ struct Progress {
 
 // brute_force_matcher.cc:36-37: the Match records are built on the host, observations never
 // leave it.
-void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int32_t n) {
-  Matches& out = *job.out;
+void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int32_t n, Matches& out) {
+  out.clear();
   out.reserve((size_t)n);
   for (int32_t m = 0; m < n; m++) {
     const IndexT i = lhs[m], j = rhs[m];
@@ -63,7 +75,8 @@ void materialise(const PairJob& job, const int32_t* lhs, const int32_t* rhs, int
 // Two sets of pinned result buffers alternate, so the GPU works on batch b (with batch b+1 queued
 // behind it) while this thread turns batch b-1 into Match records.
 void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<size_t>& shard, double ratio, bool cross,
-                int engine, Progress& progress, int helpers, sfm_hip_ctx* resident_ctx) {
+                int engine, Progress& progress, int helpers, sfm_hip_ctx* resident_ctx,
+                const HipBruteForceMatcher::MatchSink& sink, HostWork& work) {
   // resident_ctx: a context that already holds every image (replication by collective); this worker
   // takes it over.  Otherwise the worker makes its own and uploads what its shard names.
   sfm_hip_ctx* ctx = resident_ctx;
@@ -147,10 +160,18 @@ void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<
     const size_t n = std::min(batch, n_jobs - b0);
     const size_t n_helpers = std::min<size_t>((size_t)helpers, n);
     auto part = [&](size_t t) {
+      const auto t0 = std::chrono::steady_clock::now();
+      uint64_t pairs_done = 0, records = 0;
       for (size_t k = t; k < n; k += n_helpers) {
-        materialise(jobs[order[b0 + k]], s.lhs + k * stride, s.rhs + k * stride, s.counts[k]);
+        const PairJob& job = jobs[order[b0 + k]];
+        Matches list;
+        materialise(job, s.lhs + k * stride, s.rhs + k * stride, s.counts[k], list);
+        records += list.size();
+        pairs_done++;
+        sink(job.pair, std::move(list));   // the list is the sink's now: kept, forwarded or dropped
         progress.pair_finished();
       }
+      work.add(pairs_done, records, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     };
     std::vector<std::thread> pool;
     std::vector<std::exception_ptr> failed(n_helpers);
@@ -196,6 +217,18 @@ void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<
 void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs, bool is_cross_valid) {
   // brute_force_matcher.cc:10-12: every pair starts from an empty list
   for (const Pair& pair : pairs) sfm_data.matches[pair] = Matches();
+  // brute_force_matcher.cc:80,83: the finished list becomes sfm_data.matches[pair].  The map's
+  // entries exist already (above), so helper threads never change the map's structure and each
+  // writes a different entry.
+  std::map<Pair, Matches*> slot;
+  for (const Pair& pair : pairs) slot.emplace(pair, &sfm_data.matches.at(pair));
+  MatchStream(sfm_data, pairs, is_cross_valid, [&slot](const Pair& pair, Matches&& list) { *slot.at(pair) = std::move(list); });
+}
+
+void HipBruteForceMatcher::MatchStream(SfMData& sfm_data, const std::set<Pair>& pairs, bool is_cross_valid,
+                                       const MatchSink& sink) {
+  host_stats_ = HostStats{};
+  if (!sink) throw std::invalid_argument("HipBruteForceMatcher::MatchStream: empty sink");
   if (pairs.empty()) return;
   // brute_force_matcher.cc:47-50 reads through map::operator[], which creates empty entries
   for (const Pair& pair : pairs) {
@@ -228,8 +261,7 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
   jobs.reserve(pairs.size());
   for (const Pair& pair : pairs)
     jobs.push_back(PairJob{pair, &sfm_data.descriptors.at(pair.first), &sfm_data.descriptors.at(pair.second),
-                           &sfm_data.key_points.at(pair.first), &sfm_data.key_points.at(pair.second),
-                           &sfm_data.matches.at(pair)});
+                           &sfm_data.key_points.at(pair.first), &sfm_data.key_points.at(pair.second)});
   // SFM_HIP_OVERSUBSCRIBE=1 lets more shards than GPUs run (shard d on GPU d modulo the number
   // of GPUs, each with its own context and host thread): a way to exercise the multi-GPU path on
   // a machine with fewer GPUs, not a way to go faster.
@@ -239,7 +271,9 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
 
   // host threads that turn index lists into Match records, per GPU
   const unsigned cores = std::thread::hardware_concurrency();
-  const int helpers = (int)std::max(1u, std::min(8u, (cores ? cores : 8u) / (unsigned)n_dev));
+  int helpers = (int)std::max(1u, std::min(8u, (cores ? cores : 8u) / (unsigned)n_dev));
+  if (helper_threads_ > 0) helpers = helper_threads_;
+  else if (const char* env = std::getenv("SFM_HIP_HELPERS")) helpers = std::max(1, std::atoi(env));
   // Static shards: compact 2-D blocks of the (first, second) triangle of equal cost, where a pair
   // costs rows(first) x rows(second) (sfm_hip_partition_pairs); a GPU uploads only its block's images.
   std::vector<std::vector<size_t>> shards((size_t)n_dev);
@@ -315,19 +349,23 @@ void HipBruteForceMatcher::Match(SfMData& sfm_data, const std::set<Pair>& pairs,
   Progress progress;
   progress.total = (int)jobs.size();
   progress.print = print_progress_;
+  HostWork work;
   std::vector<std::thread> workers;
   std::vector<std::exception_ptr> errors((size_t)n_dev);
   for (int d = 0; d < n_dev; d++) {
     workers.emplace_back([&, d] {
       try {
         run_device(d % visible, jobs, shards[(size_t)d], ratio_, is_cross_valid, engine, progress, helpers,
-                   resident[(size_t)d]);
+                   resident[(size_t)d], sink, work);
       } catch (...) {
         errors[(size_t)d] = std::current_exception();
       }
     });
   }
   for (auto& t : workers) t.join();
+  host_stats_ = work.total;
+  host_stats_.gpus = n_dev;
+  host_stats_.helper_threads_per_gpu = helpers;
   for (auto& e : errors)
     if (e) std::rethrow_exception(e);
 }

@@ -318,3 +318,27 @@ def test_gpu_geometry_filter_program(tmp_path, devices):
         assert rec["li"].tolist() == idx.tolist()
         assert rec["ri"].tolist() == (len(l) - 1 - idx).tolist()
         assert rec["lx"].tolist() == l[idx, 0].tolist() and rec["ry"].tolist() == r[idx, 1].tolist()
+
+
+@pytest.mark.gpu
+def test_gpu_match_stream_hands_out_the_records_match_stores(tmp_path):
+    """HipBruteForceMatcher::MatchStream (bounded memory: every finished pair's list goes to a sink and
+    is not kept) against Match (brute_force_matcher.cc:80,83: everything into sfm_data.matches), on the
+    same synthetic set, three shards on the one GPU: the same records pair by pair (a checksum over
+    every record's indices and position), observations taken from the right key points, and nothing
+    left in sfm_data.matches by the streaming form."""
+    import json
+    exe = os.path.join(ROOT, "sfm_amd", "lib", "match_set_bench")
+    assert os.path.exists(exe), "run python -m sfm_amd.build"
+    env = dict(os.environ, SFM_HIP_OVERSUBSCRIBE="1")
+    lines = {}
+    for sink in ("store", "discard"):
+        out = subprocess.run([exe, "9", "700", "0.5", "3", "-1", "brute", sink], check=True, env=env,
+                             stdout=subprocess.PIPE, text=True).stdout
+        lines[sink] = json.loads(out.strip().splitlines()[-1])
+    s, d = lines["store"], lines["discard"]
+    assert s["pairs"] == d["pairs"] == 36 and s["matches"] == d["matches"] and s["matches"] >= 36 * 300
+    assert s["records_checksum"] == d["records_checksum"]
+    assert s["observation_mismatches"] == d["observation_mismatches"] == 0
+    assert s["lists_in_sfm_data"] == 36 and d["lists_in_sfm_data"] == 0
+    assert d["match_records"] == d["matches"] and d["gpus"] == 3
