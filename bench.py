@@ -42,6 +42,26 @@ PLANTED = 4096
 PEAK_FP32_MFMA_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_FP16_MFMA_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (dense)
 PEAK_HBM_GBPS = 8000.0          # HBM3E
+# fp64 vector instructions: a SIMD issues one 64-lane instruction in four cycles (16 lanes per clock);
+# 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-operations per second.  (The 78.6 TFLOP/s fp64 vector
+# figure is twice this: it counts a fused multiply-add as two, and nothing here may be fused.)
+PEAK_FP64_VALU_TOPS = 39.3
+PEAK_VALU_TOPS = 39.3           # 32-bit vector instructions issue at the same rate: 16 lanes per clock and SIMD
+PEAK_GATHER_GBPS = 7400.0       # random whole rows from a table beyond the L2s (MI355X_MICROARCH.md, "Indexed rows")
+PEAK_PCIE_GBPS = 63.0           # PCIe Gen5 x16
+WALK_OPS_PER_CANDIDATE = 5      # 2 x v_xor, 2 x v_bcnt (the second accumulates), 1 x v_cmp
+# epipolar_line_error (src/solver/fundamental_solver.hpp:59-72) as the reference writes it: five
+# rows of a 3x3 product (2 mul + 2 add each), x'.l (2 mul + 2 add), two sums of two squares (3 each),
+# two divisions, their sum, num^2, the product, the comparison with 3.84
+GEO_OPS_PER_MATCH_ROUND = 5 * 4 + 4 + 3 + 3 + 2 + 1 + 1 + 1 + 1
+# the eight-point fit of one round (fundamental_solver.cc:13-53) in this build's convention: the
+# 8 x 9 design matrix (32 products), the upper triangle of A^T A (45 entries x 16), twelve cyclic
+# Jacobi sweeps of the 9 x 9 problem (36 rotations: 19 operations for the angle, 16 element pairs x
+# 6), eight sweeps of the 3 x 3 problem of the rank-two step (3 rotations: 19 + 4 pairs x 6), the
+# final 3 x 3 update.  Divisions and square roots count as one operation each; a rotation the
+# solver skips because its entry has vanished still counts (the algorithmic figure is the
+# convention's, not what a converged wavefront executes).
+GEO_OPS_PER_FIT = 32 + 45 * 16 + 12 * 36 * (19 + 16 * 6) + 8 * 3 * (19 + 4 * 6) + 30 + 33
 
 
 def host_cores():
@@ -123,8 +143,41 @@ def cascade_leg(m, with_cpu, n_images=32, reps=40):
         m.cascade_match_pairs_async(pairs, True, stride=N_FEATURES)
         m.sync()
     st = m.cascade_stats()
-    m.set_profiling(False)
     gbps = st["match_bytes"] / (st["match_ms"] * 1e-3) / 1e9
+    # the same once more with an event between every two kernels and the kernels counting their work
+    m.set_profiling(2)
+    m.cascade_reset_stats()
+    for _ in range(reps):
+        m.cascade_match_pairs_async(pairs, True, stride=N_FEATURES)
+        m.sync()
+    sk = m.cascade_stats()
+    m.set_profiling(False)
+    nb = max(1, sk["match_launches"])
+
+    def kernel_roof(kernel, bound, achieved, peak, unit, ms, **more):
+        r = {"kernel": kernel, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+             "frac": achieved / peak, "ms_per_batch": ms}
+        r.update(more)
+        return r
+
+    # One roofline per kernel of a batch, each against the limit that binds it (an event between every
+    # two kernels of the batches above).  Walk: instruction issue -- per candidate two XORs, two
+    # population counts (the second adds the first), one comparison, on 64-bit halves of the hash
+    # codes staged in LDS.  Nearest: random 512-byte rows gathered from the images' descriptors (the
+    # set's 128 MiB; MI355X_MICROARCH.md "Indexed rows", 151 MB table: 7.4-7.9 TB/s).  Compaction: its
+    # stores go straight into the caller's pinned host memory, over PCIe (Gen5 x16, 63 GB/s).
+    walk_ms, near_ms, comp_ms = sk["walk_ms"] / nb, sk["nearest_ms"] / nb, sk["compact_ms"] / nb
+    cand, close = sk["walk_candidates"] / nb, sk["close_pairs"] / nb
+    out_bytes = n_matches * 12.0 + len(pairs) * 8.0
+    per_kernel = [
+        kernel_roof("k_ch_walk_count", "vector instruction issue", cand * WALK_OPS_PER_CANDIDATE / (walk_ms * 1e-3) / 1e12,
+                    PEAK_VALU_TOPS, "Tops/s (32-bit lane-operations)", walk_ms, candidates_per_batch=cand,
+                    ops_per_candidate=WALK_OPS_PER_CANDIDATE),
+        kernel_roof("k_ch_nearest", "random gather of 512-byte rows", close * 1024.0 / (near_ms * 1e-3) / 1e9,
+                    PEAK_GATHER_GBPS, "GB/s", near_ms, close_pairs_per_batch=close, bytes_per_close_pair=1024),
+        kernel_roof("k_ch_compact", "pcie", out_bytes / (comp_ms * 1e-3) / 1e9, PEAK_PCIE_GBPS, "GB/s", comp_ms,
+                    bytes_to_host_per_batch=out_bytes),
+    ]
     # HBM-side bytes of one such batch from a separate hardware-counter run of this workload
     # (tools/collect_cascade_profiles.sh), kept beside the profiles
     traffic = None
@@ -142,7 +195,9 @@ def cascade_leg(m, with_cpu, n_images=32, reps=40):
                         "bytes_per_batch": st["match_bytes"] / st["match_launches"],
                         "traffic_over_algorithmic": (traffic / (st["match_bytes"] / st["match_launches"])) if traffic else None,
                         "avg_batch_ms": st["match_ms"] / st["match_launches"],
-                        "bytes_per_pair": st["match_bytes"] / (reps * len(pairs))}}
+                        "bytes_per_pair": st["match_bytes"] / (reps * len(pairs))},
+           "roofline_per_kernel": per_kernel, "fallback_kernels_ms_per_batch": sk["fallback_ms"] / nb,
+           "batch_ms_with_per_kernel_events": sk["match_ms"] / nb}
     if with_cpu:
         sub = {i: d for i, d in zip(ids[:4], imgs[:4])}
         sp = [(a, b) for k, a in enumerate(ids[:4]) for b in ids[k + 1:4]]
@@ -150,6 +205,65 @@ def cascade_leg(m, with_cpu, n_images=32, reps=40):
         leg["cpu_baseline"] = cascade_cpu_baseline(sub, sp, m.cascade_match_pairs(sp, True))
     for i in ids:
         m.drop(i)
+    return leg
+
+
+def geometry_leg(m, with_cpu, n_pairs=496, n_matches=1000, reps=3, cpu_pairs=(200, 50)):
+    """Geometric verification of matches (the step that consumes the matcher's output:
+    GeometryFilter, src/sfm_main.cc:259-282; Ransac<...>::Inference, src/ransac.hpp:94-150) on the
+    same GPU: 496 pairs x 1,000 matches per C-ABI call, synthetic two-view geometry with +-0.3 px
+    noise, at 70 % planted inliers (the stopping rule ends a pair after a few hundred rounds) and at
+    40 % (every pair runs all 4,096 rounds).  value = pairs per second of the whole blocking call,
+    upload of the positions and download of the flags included.  The rooflines are per kernel,
+    against the rate at which the SIMDs can issue fp64 vector instructions; the work is counted by
+    the library (rounds fitted, (match, round) pairs measured) and priced at the operation counts
+    of the reference's own formulas."""
+    from sfm_amd import synth
+    leg = {"step": "geometric verification (RANSAC over the eight-point fundamental-matrix fit)", "cases": []}
+    for inliers, n_cpu in zip((0.7, 0.4), cpu_pairs):
+        sets = [synth.make_two_view_matches(n_matches, inliers, seed=500 + k, noise=0.3)[:2] for k in range(n_pairs)]
+        offsets = np.zeros(n_pairs + 1, np.int64)
+        offsets[1:] = np.cumsum([len(l) for l, _ in sets])
+        lhs = np.concatenate([l for l, _ in sets])
+        rhs = np.concatenate([r for _, r in sets])
+        F, flags, counts, rounds = m.geometry_verify_flat(offsets, lhs, rhs, seed=1)   # warm-up, and the results
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.geometry_verify_flat(offsets, lhs, rhs, seed=1)
+        dt = (time.perf_counter() - t0) / reps
+        m.set_profiling(True)
+        m.geometry_reset_stats()
+        m.geometry_verify_flat(offsets, lhs, rhs, seed=1)
+        st = m.geometry_stats()
+        m.set_profiling(False)
+        fit_ops, count_ops = st["rounds"] * GEO_OPS_PER_FIT, st["match_rounds"] * GEO_OPS_PER_MATCH_ROUND
+
+        def roof(kernel, ops, ms):
+            a = ops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"bound": "fp64 vector instruction issue", "kernel": kernel, "achieved": a, "peak": PEAK_FP64_VALU_TOPS,
+                    "unit": "Tops/s (fp64 lane-operations, unfused)", "frac": a / PEAK_FP64_VALU_TOPS, "traffic": None,
+                    "ms_per_call": ms, "ops_per_call": ops}
+
+        case = {"workload": "%d pairs x %d matches, %.0f %% planted inliers, one call" % (n_pairs, n_matches, 100 * inliers),
+                "value": n_pairs / dt, "unit": "pairs/s", "seconds_per_call": dt,
+                "accepted_pairs": int((counts > 30).sum()), "ransac_rounds_mean": float(rounds.mean()),
+                "ransac_rounds_max": int(rounds.max()), "inliers_mean": float(counts.mean()),
+                "rounds_worked_on": st["rounds"], "timed_launches": st["timed_launches"],
+                "ops_per_fit": GEO_OPS_PER_FIT, "ops_per_match_and_round": GEO_OPS_PER_MATCH_ROUND,
+                "roofline": [roof("k_geo_fit", fit_ops, st["fit_ms"]), roof("k_geo_count", count_ops, st["count_ms"])]}
+        if with_cpu and n_cpu > 0:
+            from oracle import geometry   # the checker, timed as the CPU baseline on a bounded sample
+            t0 = time.perf_counter()
+            same = True
+            for k in range(n_cpu):
+                ok, oF, oflags, r = geometry.compute_fundamental(sets[k][0], sets[k][1], seed=1, pair=k)
+                mine = flags[offsets[k]:offsets[k + 1]]
+                same = same and ok == (int(counts[k]) > 30) and r == int(rounds[k]) and oflags.tolist() == mine.tolist() \
+                    and oF.reshape(-1).view(np.uint64).tolist() == F[k].view(np.uint64).tolist()
+            dc = time.perf_counter() - t0
+            case["cpu_baseline"] = {"value": n_cpu / dc, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                    "sample": "the first %d pairs of the same call" % n_cpu, "equal_to_gpu": bool(same)}
+        leg["cases"].append(case)
     return leg
 
 
@@ -516,6 +630,8 @@ def main():
                     help="do not time the 64-pairs-per-call leg after the main run")
     ap.add_argument("--no-cascade", action="store_true",
                     help="do not time the cascade-hash matcher after the main run")
+    ap.add_argument("--no-geometry", action="store_true",
+                    help="do not time the geometric verification of matches after the main run")
     ap.add_argument("--untimed-pass", action="store_true",
                     help="after the timed region, run the same K steps once more without per-launch kernel "
                          "timing and report that rate as an extra field")
@@ -831,6 +947,11 @@ def main():
                 line["cascade_hash"] = cascade_leg(m, not args.no_cpu_baseline)
             except Exception as e:   # an extra, never the reason the headline line is lost
                 line["cascade_hash"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_geometry:
+            try:
+                line["geometry"] = geometry_leg(m, not args.no_cpu_baseline)
+            except Exception as e:   # an extra, never the reason the headline line is lost
+                line["geometry"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if line is not None:
         print(json.dumps(line), flush=True)
 

@@ -217,7 +217,10 @@ void sfm_hip_host_free(void* p);
  * timed from that launch's completion to its own (both events ride on the kernels' dispatch
  * packets; the microseconds between two launches count in); one that finds the stream idle gets a
  * start event of its own, a packet in front of the kernel that costs a few microseconds.
- * sfm_hip_get_stats() waits for the queued work and folds the durations into distance_ms. */
+ * sfm_hip_get_stats() waits for the queued work and folds the durations into distance_ms.
+ * enabled = 2 additionally puts an event between every two kernels of a cascade-hash batch and has
+ * those kernels count their work (the per-kernel fields of sfm_hip_cascade_stats); each such event
+ * is a packet of its own and costs the batch a few microseconds. */
 int sfm_hip_set_profiling(sfm_hip_ctx* ctx, int enabled);
 int sfm_hip_get_stats(sfm_hip_ctx* ctx, sfm_hip_stats* out);
 int sfm_hip_reset_stats(sfm_hip_ctx* ctx);
@@ -255,6 +258,15 @@ typedef struct {
                                the slower path that needs no list */
   uint64_t workspace_dirty_words; /* non-zero words found in the per-query work space, which every
                                batch leaves all zeros: anything but 0 is a defect */
+  /* Of the batches timed with sfm_hip_set_profiling(ctx, 2), per kernel: */
+  double walk_ms;           /* k_ch_walk_count */
+  double nearest_ms;        /* k_ch_nearest */
+  double fallback_ms;       /* k_ch_take_all + k_ch_walk_nearest (both return at once unless a list overflowed) */
+  double compact_ms;        /* k_ch_compact */
+  uint64_t walk_candidates; /* (first-image descriptor, second-image descriptor, group) triples that share a
+                               bucket: what the walk tests, each by the Hamming distance of two 64-bit halves */
+  uint64_t close_pairs;     /* entries of the close-pair lists (Hamming distance <= 10): each costs the exact
+                               distance of two 512-byte descriptor rows unless neither side takes its bin */
 } sfm_hip_cascade_stats;
 
 /* The projection matrices of cascade_hash_matcher.cc:130-146: primary[128][128] (row i produces hash
@@ -342,6 +354,24 @@ int sfm_hip_cascade_reset_stats(sfm_hip_ctx* ctx);
 int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64_t* match_offsets, const double* lhs_xy,
                                   const double* rhs_xy, uint64_t seed, int64_t first_pair_index, double* out_F,
                                   uint8_t* out_inlier_flags, int32_t* out_inlier_counts, int32_t* out_rounds);
+
+/* Counters of the geometric verification since context creation or the last reset.  The work
+ * counters and the durations are collected only while profiling is enabled (sfm_hip_set_profiling):
+ * every launch of 256 rounds is then bracketed with HIP events on the stream it runs on, one in
+ * front of the fit, one between fit and count, one behind the count. */
+typedef struct {
+  uint64_t calls;          /* calls of sfm_hip_geometry_verify_pairs */
+  uint64_t pairs;          /* pairs with at least eight matches among them */
+  uint64_t timed_launches; /* launches (fit + count of up to 256 rounds of every unfinished pair) that were timed */
+  uint64_t rounds;         /* RANSAC rounds those launches sampled, fitted and counted: more than the
+                              rounds the pairs report, since a launch works on 256 rounds of a pair at once
+                              and the rounds behind the pair's stopping point are discarded */
+  uint64_t match_rounds;   /* (match, round) pairs the count measured: sum over those rounds of the pair's matches */
+  double fit_ms;           /* summed duration of the timed launches' k_geo_fit */
+  double count_ms;         /* ... and of their k_geo_count */
+} sfm_hip_geometry_stats;
+int sfm_hip_geometry_get_stats(sfm_hip_ctx* ctx, sfm_hip_geometry_stats* out);
+int sfm_hip_geometry_reset_stats(sfm_hip_ctx* ctx);
 
 #ifdef __cplusplus
 }

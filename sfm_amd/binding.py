@@ -20,7 +20,8 @@ EXPORTS = (
     "sfm_hip_cascade_set_projection", "sfm_hip_cascade_column_sums", "sfm_hip_cascade_hash_images",
     "sfm_hip_cascade_get_hashes", "sfm_hip_cascade_match_pairs", "sfm_hip_cascade_reference_projection",
     "sfm_hip_cascade_image_order", "sfm_hip_cascade_prepare", "sfm_hip_cascade_get_stats",
-    "sfm_hip_cascade_reset_stats", "sfm_hip_geometry_verify_pairs",
+    "sfm_hip_cascade_reset_stats", "sfm_hip_geometry_verify_pairs", "sfm_hip_geometry_get_stats",
+    "sfm_hip_geometry_reset_stats",
 )
 
 CASCADE_GROUPS, CASCADE_GROUP_BITS, CASCADE_CODE_BITS = 6, 10, 128
@@ -44,7 +45,15 @@ class ReplicateTimes(ctypes.Structure):
 class CascadeStats(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_uint64), ("images_hashed", ctypes.c_uint64), ("match_launches", ctypes.c_uint64),
                 ("match_ms", ctypes.c_double), ("match_bytes", ctypes.c_double),
-                ("list_overflows", ctypes.c_uint64), ("workspace_dirty_words", ctypes.c_uint64)]
+                ("list_overflows", ctypes.c_uint64), ("workspace_dirty_words", ctypes.c_uint64),
+                ("walk_ms", ctypes.c_double), ("nearest_ms", ctypes.c_double), ("fallback_ms", ctypes.c_double),
+                ("compact_ms", ctypes.c_double), ("walk_candidates", ctypes.c_uint64), ("close_pairs", ctypes.c_uint64)]
+
+
+class GeometryStats(ctypes.Structure):
+    _fields_ = [("calls", ctypes.c_uint64), ("pairs", ctypes.c_uint64), ("timed_launches", ctypes.c_uint64),
+                ("rounds", ctypes.c_uint64), ("match_rounds", ctypes.c_uint64),
+                ("fit_ms", ctypes.c_double), ("count_ms", ctypes.c_double)]
 
 
 def library_path():
@@ -105,6 +114,8 @@ def library():
     lib.sfm_hip_cascade_get_stats.argtypes = [vp, ctypes.POINTER(CascadeStats)]
     lib.sfm_hip_cascade_reset_stats.argtypes = [vp]
     lib.sfm_hip_geometry_verify_pairs.argtypes = [vp, i32, vp, vp, vp, ctypes.c_uint64, i64, vp, vp, vp, vp]
+    lib.sfm_hip_geometry_get_stats.argtypes = [vp, ctypes.POINTER(GeometryStats)]
+    lib.sfm_hip_geometry_reset_stats.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -424,12 +435,22 @@ class Matcher:
         return [(int(counts[k]) > 30, F[k].reshape(3, 3).copy(), flags[offsets[k]:offsets[k + 1]].copy(), int(rounds[k]))
                 for k in range(len(matches))]
 
+    def geometry_stats(self):
+        s = GeometryStats()
+        self._check(self._lib.sfm_hip_geometry_get_stats(self._h, ctypes.byref(s)), "sfm_hip_geometry_get_stats")
+        return {f: getattr(s, f) for f, _ in GeometryStats._fields_}
+
+    def geometry_reset_stats(self):
+        self._check(self._lib.sfm_hip_geometry_reset_stats(self._h), "sfm_hip_geometry_reset_stats")
+
     def set_engine(self, name):
         """'f32' (fp32 matrix instructions) or 'f16x3' (split fp16 products): include/sfm_hip.h."""
         self._check(self._lib.sfm_hip_set_engine(self._h, ENGINES[name]), "sfm_hip_set_engine")
 
     def set_profiling(self, on):
-        self._check(self._lib.sfm_hip_set_profiling(self._h, int(bool(on))), "sfm_hip_set_profiling")
+        """False/True, or 2: per-kernel events and work counters in cascade-hash batches as well."""
+        self._check(self._lib.sfm_hip_set_profiling(self._h, 2 if on == 2 and on is not True else int(bool(on))),
+                    "sfm_hip_set_profiling")
 
     def stats(self):
         s = Stats()

@@ -394,6 +394,7 @@ constexpr int WALK_THREADS = 256;
 constexpr int WALK_CHUNK = 512;      // staged records of the second image per step
 constexpr int LIST_SEGMENT = 128;    // close pairs a workgroup can report
 
+constexpr uint32_t WORK_SLOTS = 1024; // counters the statistics of a walk are spread over
 constexpr int WALK_QUEUE = 256;      // candidates per wavefront and staged chunk that pass the first test
 
 struct WalkShared {
@@ -452,7 +453,7 @@ __device__ __forceinline__ void finish_queue(const CascadePair& P, int g, int bo
 // The work of workgroup bx of nbx for (pair P, group g).
 template <int MODE>
 __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, int nbx, int both_directions,
-                                           WalkShared& sh) {
+                                           WalkShared& sh, unsigned long long* __restrict__ work = nullptr) {
   uint2* stage_lo = sh.lo;
   int* range = sh.range;
   const int na = P.na, nb = P.nb;
@@ -481,6 +482,12 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
     sh.n_found = 0;
   }
   if (p == min(p0 + WALK_THREADS - 1, na - 1)) range[1] = e;
+  if (work) {   // statistics only: candidates this wavefront will test, into one of WORK_SLOTS counters
+    unsigned long long mine = (unsigned long long)(e - s);   // (a single counter would serialise the launch's atomics)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((tid & 63) == 0 && mine) atomicAdd(work + ((seg * 4u + (uint32_t)(tid >> 6) + (uint32_t)P.out_slot * 37u) & (WORK_SLOTS - 1)), mine);
+  }
   __syncthreads();
 #if defined(SFM_ABLATE_WALK_UPTO) && SFM_ABLATE_WALK_UPTO <= 1   // timing experiments only (tools/build_variant.sh)
   const int lo = 0, hi = lo_half.x == 0x12345678u ? range[1] : 0;
@@ -543,9 +550,11 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
 }
 
 // COUNT: grid (ceil(largest na of the batch / 256), 6, pairs), one workgroup per 256 records.
-__global__ __launch_bounds__(WALK_THREADS) void k_ch_walk_count(const CascadePair* __restrict__ pairs, int both_directions) {
+// work (may be null): counter that receives the number of candidates tested, for the statistics.
+__global__ __launch_bounds__(WALK_THREADS) void k_ch_walk_count(const CascadePair* __restrict__ pairs, int both_directions,
+                                                                unsigned long long* __restrict__ work) {
   __shared__ WalkShared sh;
-  walk_block<WALK_COUNT>(pairs[blockIdx.z], blockIdx.y, blockIdx.x, gridDim.x, both_directions, sh);
+  walk_block<WALK_COUNT>(pairs[blockIdx.z], blockIdx.y, blockIdx.x, gridDim.x, both_directions, sh, work);
 }
 
 // NEAREST: grid (a few, 6, pairs); returns at once unless the pair's list overflowed, else the
@@ -572,8 +581,9 @@ constexpr int NEAREST_MAX_SEGMENTS = GROUPS * (MAX_IMAGE_ROWS / 256);
 constexpr int NEAREST_TILE = 64;
 constexpr int NEAREST_SQ_STRIDE = 132;   // words per row of squares (128 + 4: conflict-free 16-byte reads)
 
+// work (may be null): counter that receives the number of list entries, for the statistics.
 __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __restrict__ pairs, int both_directions,
-                                                       int segments) {
+                                                       int segments, unsigned long long* __restrict__ work) {
   extern __shared__ uint32_t start[];   // start[s] = entries in the segments before s
   __shared__ uint32_t wave_sum[4];
   __shared__ __attribute__((aligned(16))) float sq[NEAREST_TILE * NEAREST_SQ_STRIDE];
@@ -608,6 +618,7 @@ __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __rest
   if (tid == 255) start[segments] = before;   // the last thread ends up with the total
   __syncthreads();
   const uint32_t total = start[segments];
+  if (work && blockIdx.x == 0 && tid == 0 && total) atomicAdd(work, (unsigned long long)total);
   for (uint32_t t0 = blockIdx.x * NEAREST_TILE; t0 < total; t0 += gridDim.x * NEAREST_TILE) {
     // one lane per entry: the bins decisions
     if (tid < NEAREST_TILE) {

@@ -115,6 +115,7 @@ struct sfm_hip_ctx {
 
   int engine = SFM_HIP_ENGINE_F32;
   bool profiling = false;
+  bool profiling_per_kernel = false;   // cascade-hash batches: an event between every two kernels, and the work counters
   std::vector<sfm_host::TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
   std::vector<void*> retired;                   // outgrown work-space buffers, freed at the next drain
@@ -129,12 +130,14 @@ struct sfm_hip_ctx {
   sfm_host::DevBuf geometry_buffers[11];
   hipStream_t geometry_readback = nullptr;   // reads a launch's "unfinished" counter while the next launch runs
   hipEvent_t geometry_events[16] = {};       // one per launch of a call
+  sfm_hip_geometry_stats geometry_stats{};
 
   // cascade-hash matcher
   float* cascade_projection = nullptr;   // device: [128 + 60][128] projection rows, then the 128-float mean
   bool cascade_has_projection = false;
   unsigned long long* cascade_counters = nullptr;   // device: {pairs whose list overflowed, scratch for checks}
-  std::vector<hipEvent_t> cascade_timing;   // start/stop pairs of timed cascade match batches
+  std::vector<hipEvent_t> cascade_timing;   // five events per timed cascade match batch (the middle three only per kernel)
+  std::vector<char> cascade_timing_per_kernel;   // per timed batch: were the middle three recorded
   sfm_hip_cascade_stats cascade_stats{};
 };
 

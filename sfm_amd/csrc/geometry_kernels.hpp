@@ -344,8 +344,11 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return v;
 }
 
+// `work` (may be null): two counters that receive the rounds this launch's fit and count worked on
+// and the (match, round) pairs the count measured -- for the statistics, not for the result.
 __global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restrict__ pairs, int n_pairs,
-                                                        uint32_t* __restrict__ unfinished) {
+                                                        uint32_t* __restrict__ unfinished,
+                                                        unsigned long long* __restrict__ work) {
   static_assert(ROUNDS_PER_LAUNCH == 256, "four slots per lane");
   const int p = blockIdx.x;
   if (p >= n_pairs) return;
@@ -355,6 +358,11 @@ __global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restric
   const uint32_t limit0 = st->rounds_limit, done0 = st->rounds_done, best0 = st->best_count;
   const int l = threadIdx.x;
   const uint32_t NONE = 0xFFFFFFFFu;
+  if (work && l == 0 && limit0 > done0) {   // the launch started at round done0 and skipped rounds at or beyond limit0
+    const unsigned long long worked = min(limit0 - done0, (uint32_t)ROUNDS_PER_LAUNCH);
+    atomicAdd(work, worked);
+    atomicAdd(work + 1, worked * (unsigned long long)P.n);
+  }
   uint32_t cnt[4], need[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) cnt[k] = P.hyp_count[4 * l + k];

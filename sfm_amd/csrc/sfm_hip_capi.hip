@@ -871,6 +871,7 @@ int sfm_hip_set_engine(sfm_hip_ctx* ctx, int engine) {
 int sfm_hip_set_profiling(sfm_hip_ctx* ctx, int enabled) {
   if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
   ctx->profiling = enabled != 0;
+  ctx->profiling_per_kernel = enabled >= 2;
   return SFM_HIP_OK;
 }
 

@@ -46,16 +46,29 @@ int find_images(sfm_hip_ctx* ctx, const int64_t* ids, int32_t n, std::vector<Ima
   return SFM_HIP_OK;
 }
 
+// Events of a timed batch: in front of the walk, behind it, behind the nearest kernel, behind the
+// two fallback kernels, behind the compaction.
+constexpr size_t BATCH_MARKS = 5;
+// cascade_counters: list overflows, scratch for checks, close pairs, -, then the walk's candidate counters
+constexpr int N_COUNTERS = 4 + (int)WORK_SLOTS;
+
 int fold_cascade_timing(sfm_hip_ctx* ctx) {
-  for (size_t k = 0; k + 1 < ctx->cascade_timing.size(); k += 2) {
-    float ms = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cascade_timing[k], ctx->cascade_timing[k + 1]));
-    ctx->cascade_stats.match_ms += ms;
+  for (size_t k = 0; k + BATCH_MARKS <= ctx->cascade_timing.size(); k += BATCH_MARKS) {
+    const hipEvent_t* e = &ctx->cascade_timing[k];
+    float whole = 0.f, part[BATCH_MARKS - 1] = {};
+    HIP_TRY(ctx, hipEventElapsedTime(&whole, e[0], e[BATCH_MARKS - 1]));
+    if (ctx->cascade_timing_per_kernel[k / BATCH_MARKS])
+      for (size_t q = 0; q + 1 < BATCH_MARKS; q++) HIP_TRY(ctx, hipEventElapsedTime(&part[q], e[q], e[q + 1]));
+    ctx->cascade_stats.match_ms += whole;
+    ctx->cascade_stats.walk_ms += part[0];
+    ctx->cascade_stats.nearest_ms += part[1];
+    ctx->cascade_stats.fallback_ms += part[2];
+    ctx->cascade_stats.compact_ms += part[3];
     ctx->cascade_stats.match_launches += 1;
-    ctx->event_pool.push_back(ctx->cascade_timing[k]);
-    ctx->event_pool.push_back(ctx->cascade_timing[k + 1]);
   }
+  for (hipEvent_t e : ctx->cascade_timing) ctx->event_pool.push_back(e);
   ctx->cascade_timing.clear();
+  ctx->cascade_timing_per_kernel.clear();
   return SFM_HIP_OK;
 }
 
@@ -261,8 +274,8 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
   }
 
   if (!ctx->cascade_counters) {
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->cascade_counters, 2 * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemset(ctx->cascade_counters, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->cascade_counters, N_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemset(ctx->cascade_counters, 0, N_COUNTERS * sizeof(unsigned long long)));
   }
 
   int done = 0;
@@ -374,16 +387,23 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       bytes += GROUPS * ((double)X.n * (sizeof(uint2) + sizeof(uint16_t)) + (double)Y.n * sizeof(uint2)) +
                16.0 * ((double)X.n + (double)Y.n);
     }
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (ctx->profiling) {
-      t0 = take_event(ctx);
-      t1 = take_event(ctx);
-      if (!t0 || !t1) {   // no events to be had: this batch runs untimed
-        if (t0) ctx->event_pool.push_back(t0);
-        if (t1) ctx->event_pool.push_back(t1);
-        t0 = t1 = nullptr;
-      }
+    hipEvent_t marks[BATCH_MARKS] = {};
+    bool timed = ctx->profiling;
+    if (timed) {
+      for (hipEvent_t& e : marks) timed = (e = take_event(ctx)) && timed;
+      if (!timed)   // no events to be had: this batch runs untimed
+        for (hipEvent_t e : marks)
+          if (e) ctx->event_pool.push_back(e);
     }
+    // per_kernel: an event at every mark below; otherwise only in front of the first kernel and behind the last
+    const bool per_kernel = timed && ctx->profiling_per_kernel;
+    unsigned long long* work = per_kernel ? ctx->cascade_counters : nullptr;
+    size_t mark_no = 0;
+    auto mark = [&]() -> int {
+      const size_t k = mark_no++;
+      if (timed && (per_kernel || k == 0 || k == BATCH_MARKS - 1)) HIP_TRY(ctx, hipEventRecord(marks[k], st));
+      return SFM_HIP_OK;
+    };
     // Results land in call order even when calls share output memory (order_outputs, ctx.hpp).  This
     // lane's earlier batches run on the same stream and need no ordering; they may still be
     // unfinished, so what they write stays on the lane's record beside this batch's ranges.
@@ -396,16 +416,18 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     }
     HIP_TRY(ctx, hipMemcpyAsync(L.cascade_tables.p, hp, table_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipEventRecord(L.stage_free[slot], st));
-    if (t0) HIP_TRY(ctx, hipEventRecord(t0, st));
+    if ((rc = mark())) return rc;
     const CascadePair* dp = (const CascadePair*)L.cascade_tables.p;
     const int both = cross_check ? 1 : 0;
     if (max_na > 0) {
       hipLaunchKernelGGL(k_ch_walk_count, dim3((unsigned)n_walk, GROUPS, (unsigned)count), dim3(WALK_THREADS), 0, st, dp,
-                         both);
+                         both, work ? work + 4 : nullptr);
       HIP_TRY(ctx, hipGetLastError());
+      if ((rc = mark())) return rc;
       hipLaunchKernelGGL(k_ch_nearest, dim3(NEAREST_BLOCKS, 1, (unsigned)count), dim3(256), (segments + 1) * sizeof(uint32_t),
-                         st, dp, both, (int)segments);
+                         st, dp, both, (int)segments, work ? work + 2 : nullptr);
       HIP_TRY(ctx, hipGetLastError());
+      if ((rc = mark())) return rc;
       // the two kernels below return at once for every pair whose list was complete
       hipLaunchKernelGGL(k_ch_take_all, dim3(FALLBACK_BLOCKS, cross_check ? 2 : 1, (unsigned)count), dim3(256), 0, st, dp,
                          ctx->cascade_counters);
@@ -413,15 +435,19 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       hipLaunchKernelGGL(k_ch_walk_nearest, dim3(FALLBACK_BLOCKS, GROUPS, (unsigned)count), dim3(WALK_THREADS), 0, st, dp,
                          both);
       HIP_TRY(ctx, hipGetLastError());
+    } else {
+      if ((rc = mark())) return rc;
+      if ((rc = mark())) return rc;
     }
+    if ((rc = mark())) return rc;
     hipLaunchKernelGGL(k_ch_compact, dim3((unsigned)count), dim3(CH_COMPACT_THREADS), 0, st, dp, both, k_defaults, k_counts, k_lhs, k_rhs,
                        k_dist, out_stride);
     HIP_TRY(ctx, hipGetLastError());
     L.cascade_slots_dirty = false;
-    if (t1) {
-      HIP_TRY(ctx, hipEventRecord(t1, st));
-      ctx->cascade_timing.push_back(t0);
-      ctx->cascade_timing.push_back(t1);
+    if ((rc = mark())) return rc;
+    if (timed) {
+      for (hipEvent_t e : marks) ctx->cascade_timing.push_back(e);
+      ctx->cascade_timing_per_kernel.push_back(per_kernel);
       ctx->cascade_stats.match_bytes += bytes;
     }
     if (!direct) {
@@ -507,10 +533,13 @@ int sfm_hip_cascade_get_stats(sfm_hip_ctx* ctx, sfm_hip_cascade_stats* out) {
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipStreamSynchronize(L.stream));
     }
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[N_COUNTERS] = {};
     HIP_TRY(ctx, hipMemcpy(c, ctx->cascade_counters, sizeof(c), hipMemcpyDeviceToHost));
     ctx->cascade_stats.list_overflows = c[0];
     ctx->cascade_stats.workspace_dirty_words = c[1];
+    ctx->cascade_stats.close_pairs = c[2];
+    ctx->cascade_stats.walk_candidates = 0;
+    for (int k = 4; k < N_COUNTERS; k++) ctx->cascade_stats.walk_candidates += c[k];
   }
   *out = ctx->cascade_stats;
   return SFM_HIP_OK;
@@ -521,7 +550,7 @@ int sfm_hip_cascade_reset_stats(sfm_hip_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (int rc = sync_all(ctx)) return rc;
   if (int rc = fold_cascade_timing(ctx)) return rc;
-  if (ctx->cascade_counters) HIP_TRY(ctx, hipMemset(ctx->cascade_counters, 0, 2 * sizeof(unsigned long long)));
+  if (ctx->cascade_counters) HIP_TRY(ctx, hipMemset(ctx->cascade_counters, 0, N_COUNTERS * sizeof(unsigned long long)));
   ctx->cascade_stats = sfm_hip_cascade_stats{};
   return SFM_HIP_OK;
 }

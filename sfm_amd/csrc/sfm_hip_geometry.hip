@@ -102,7 +102,9 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   if ((rc = grown(ctx, 7, (size_t)total, &d_flags.p))) return rc;
   if ((rc = grown(ctx, 8, (size_t)n_live * 4, &d_counts.p))) return rc;
   if ((rc = grown(ctx, 9, (size_t)n_live * sizeof(GeoPair), &d_pairs.p))) return rc;
-  if ((rc = grown(ctx, 10, 4 * 16, &d_unfinished.p))) return rc;
+  // one "unfinished" counter per launch, then the two work counters of the statistics
+  if ((rc = grown(ctx, 10, 4 * 16 + 2 * sizeof(unsigned long long), &d_unfinished.p))) return rc;
+  unsigned long long* d_work = ctx->profiling ? (unsigned long long*)((char*)d_unfinished.p + 4 * 16) : nullptr;
   HIP_TRY(ctx, hipMemcpyAsync(d_lhs.p, lhs_xy, (size_t)total * 16, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_rhs.p, rhs_xy, (size_t)total * 16, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_tables.p, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, st));
@@ -147,14 +149,39 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   if (!ctx->geometry_readback) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->geometry_readback, hipStreamNonBlocking));
   for (int k = 0; k < MAX_LAUNCHES; k++)
     if (!ctx->geometry_events[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->geometry_events[k], hipEventDisableTiming));
-  HIP_TRY(ctx, hipMemsetAsync(d_unfinished.p, 0, 4 * MAX_LAUNCHES, st));
+  HIP_TRY(ctx, hipMemsetAsync(d_unfinished.p, 0, 4 * MAX_LAUNCHES + 2 * sizeof(unsigned long long), st));
+  // profiling: three events per launch (in front of the fit, between fit and count, behind the count)
+  struct Marks {   // back into the context's pool however the call ends
+    sfm_hip_ctx* ctx;
+    std::vector<hipEvent_t> v;
+    ~Marks() { for (hipEvent_t e : v) ctx->event_pool.push_back(e); }
+  } held{ctx, {}};
+  std::vector<hipEvent_t>& marks = held.v;
+  auto mark = [&]() -> int {
+    if (!ctx->profiling) return SFM_HIP_OK;
+    hipEvent_t e = nullptr;
+    if (!ctx->event_pool.empty()) {
+      e = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+    } else {
+      HIP_TRY(ctx, hipEventCreate(&e));
+    }
+    marks.push_back(e);
+    HIP_TRY(ctx, hipEventRecord(e, st));
+    return SFM_HIP_OK;
+  };
   auto queue_launch = [&](int k) -> int {
     const uint32_t first = (uint32_t)k * ROUNDS_PER_LAUNCH;
+    int mrc;
+    if ((mrc = mark())) return mrc;
     hipLaunchKernelGGL(k_geo_fit, dim3(ROUNDS_PER_LAUNCH / HYP_THREADS, (unsigned)n_live), dim3(HYP_THREADS), 0, st, dp, first);
     HIP_TRY(ctx, hipGetLastError());
+    if ((mrc = mark())) return mrc;
     hipLaunchKernelGGL(k_geo_count, dim3((unsigned)n_live), dim3(ROUNDS_PER_LAUNCH), 0, st, dp, first);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)n_live), dim3(64), 0, st, dp, n_live, (uint32_t*)d_unfinished.p + k);
+    if ((mrc = mark())) return mrc;
+    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)n_live), dim3(64), 0, st, dp, n_live, (uint32_t*)d_unfinished.p + k,
+                       d_work);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->geometry_events[k], st));
     return SFM_HIP_OK;
@@ -174,13 +201,40 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   HIP_TRY(ctx, hipMemcpyAsync(states.data(), d_state.p, states.size() * sizeof(GeoState), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(out_inlier_flags, d_flags.p, (size_t)total, hipMemcpyDeviceToHost, st));
+  unsigned long long work[2] = {0, 0};
+  if (d_work) HIP_TRY(ctx, hipMemcpyAsync(work, d_work, sizeof(work), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->geometry_stats.calls += 1;
+  ctx->geometry_stats.pairs += (uint64_t)n_live;
+  ctx->geometry_stats.rounds += work[0];
+  ctx->geometry_stats.match_rounds += work[1];
+  for (size_t k = 0; k + 2 < marks.size(); k += 3) {
+    float fit = 0.f, count = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&fit, marks[k], marks[k + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&count, marks[k + 1], marks[k + 2]));
+    ctx->geometry_stats.fit_ms += fit;
+    ctx->geometry_stats.count_ms += count;
+    ctx->geometry_stats.timed_launches += 1;
+  }
   for (int k = 0; k < n_live; k++) {
     const int32_t p = live[(size_t)k];
     for (int c = 0; c < 9; c++) out_F[(size_t)p * 9 + c] = states[(size_t)k].best_F[c];
     out_inlier_counts[p] = (int32_t)counts[(size_t)k];
     if (out_rounds) out_rounds[p] = (int32_t)states[(size_t)k].rounds_done;
   }
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_geometry_get_stats(sfm_hip_ctx* ctx, sfm_hip_geometry_stats* out) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  if (!out) return fail(ctx, SFM_HIP_ERR_INVALID, "out is null");
+  *out = ctx->geometry_stats;   // the verification is a blocking call: nothing of it is ever pending
+  return SFM_HIP_OK;
+}
+
+int sfm_hip_geometry_reset_stats(sfm_hip_ctx* ctx) {
+  if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
+  ctx->geometry_stats = sfm_hip_geometry_stats{};
   return SFM_HIP_OK;
 }
 

@@ -78,4 +78,6 @@ def test_product_code_never_touches_the_oracle():
     bench = open(os.path.join(ROOT, "bench.py")).read()
     uses = [i for i, line in enumerate(bench.split("\n")) if "oracle" in line and "import" in line]
     body = bench[bench.index("def cpu_baseline"):bench.index("def replication_check")]
-    assert len(uses) == 2 and "from oracle import oracle" in body and "from oracle import cascade" in body
+    # the three CPU-baseline legs: brute force, cascade hash, geometric verification
+    assert len(uses) == 3 and "from oracle import oracle" in body and "from oracle import cascade" in body \
+        and "from oracle import geometry" in body

@@ -361,3 +361,35 @@ def test_wait_outputs_covers_an_earlier_multi_batch_call(matcher):
             for b in bufs:
                 b.free()
         matcher.drop_all()
+
+
+def test_per_kernel_statistics_leave_the_matches_alone(matcher):
+    """sfm_hip_set_profiling(ctx, 2): events between the kernels of a batch and work counters inside
+    them.  Same matches; the walk reports at least as many candidates as close pairs, and every
+    match comes from a close pair."""
+    a, b = synth.make_repetitive_set(2, 2048, 0.5, 2, seed=77, sigma=0.002)
+    images = {0: a, 1: b}
+    _upload(matcher, images)
+    matcher.cascade_prepare([(0, 1)])
+    plain = matcher.cascade_match_pairs([(0, 1)], True)
+    matcher.set_profiling(2)
+    matcher.cascade_reset_stats()
+    timed = matcher.cascade_match_pairs([(0, 1)], True)
+    st = matcher.cascade_stats()
+    matcher.set_profiling(True)
+    matcher.cascade_reset_stats()
+    light = matcher.cascade_match_pairs([(0, 1)], True)
+    st_light = matcher.cascade_stats()
+    matcher.set_profiling(False)
+    for got in (timed, light):
+        assert (got[0][0], got[0][1].tolist(), got[0][2].tolist()) == (plain[0][0], plain[0][1].tolist(), plain[0][2].tolist())
+    assert st["match_launches"] == 1 and st["walk_ms"] > 0 and st["nearest_ms"] > 0 and st["compact_ms"] > 0
+    assert st["walk_ms"] + st["nearest_ms"] + st["fallback_ms"] + st["compact_ms"] <= st["match_ms"] * 1.001
+    assert st["walk_candidates"] >= st["close_pairs"] >= len(plain[0][1]) > 50
+    # bucket sharing is symmetric: the count equals the sum over groups and buckets of |A_b| * |B_b|
+    _, bids_a = matcher.cascade_get_hashes(0)
+    _, bids_b = matcher.cascade_get_hashes(1)
+    want = sum(int(np.dot(np.bincount(bids_a[:, g], minlength=1024), np.bincount(bids_b[:, g], minlength=1024)))
+               for g in range(binding.CASCADE_GROUPS))
+    assert st["walk_candidates"] == want
+    assert st_light["match_launches"] == 1 and st_light["walk_ms"] == 0 and st_light["walk_candidates"] == 0

@@ -78,3 +78,28 @@ def test_bad_arguments_are_refused(matcher):
         matcher.geometry_verify_flat(np.array([0, 20, 10], np.int64), l, r)
     F, flags, counts, rounds = matcher.geometry_verify_flat(np.array([0], np.int64), l[:0], r[:0])
     assert len(counts) == 0 and len(flags) == 0
+
+
+def test_statistics_count_the_work_of_timed_calls(matcher):
+    """With profiling on a call reports, through sfm_hip_geometry_get_stats, the rounds its launches
+    worked on (at least the rounds the pairs report: a launch takes 256 rounds of a pair at once),
+    the (match, round) pairs measured and kernel durations; the results are the same either way."""
+    sets = [synth.make_two_view_matches(n, f, seed=70 + k)[:2] for k, (n, f) in enumerate([(300, 0.8), (500, 0.4), (5, 1.0)])]
+    plain = matcher.geometry_verify_pairs(sets, seed=2)
+    matcher.set_profiling(True)
+    matcher.geometry_reset_stats()
+    timed = matcher.geometry_verify_pairs(sets, seed=2)
+    st = matcher.geometry_stats()
+    matcher.set_profiling(False)
+    for a, b in zip(plain, timed):
+        _same(a, b)
+    rounds = [g[3] for g in timed]
+    assert st["calls"] == 1 and st["pairs"] == 2          # the pair with five matches cannot be sampled
+    assert st["timed_launches"] >= 1 and st["fit_ms"] > 0 and st["count_ms"] > 0
+    assert st["rounds"] >= sum(rounds) and st["rounds"] % 1 == 0
+    assert st["rounds"] <= sum(-(-r // 256) * 256 for r in rounds)
+    assert 300 * rounds[0] + 500 * rounds[1] <= st["match_rounds"] <= 500 * st["rounds"]
+    # without profiling nothing but the call and pair counts moves
+    matcher.geometry_verify_pairs(sets, seed=2)
+    again = matcher.geometry_stats()
+    assert again["calls"] == 2 and again["rounds"] == st["rounds"] and again["timed_launches"] == st["timed_launches"]
