@@ -42,6 +42,30 @@
 
 namespace sfm_cascade {
 
+// Pointers that arrive through a table in memory are generic to the compiler, and a generic ("flat")
+// access counts against the LDS counter as well as the memory counter, so that every wait for an
+// LDS read also waits for the loads and atomics in flight.  The walk's go through global pointers.
+#define SFM_GLOBAL_AS __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const SFM_GLOBAL_AS T* as_global(const T* p) { return (const SFM_GLOBAL_AS T*)p; }
+template <class T>
+__device__ __forceinline__ SFM_GLOBAL_AS T* as_global(T* p) { return (SFM_GLOBAL_AS T*)p; }
+// (HIP's uint2 / uint4 are classes whose copy constructors take generic references: 8- and 16-byte
+// accesses go through the compiler's native vector types)
+typedef uint32_t sfm_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t sfm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 global_load(const uint2* p) {
+  const sfm_u32x2 v = *reinterpret_cast<const SFM_GLOBAL_AS sfm_u32x2*>(as_global(p));
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 global_load(const uint4* p) {
+  const sfm_u32x4 v = *reinterpret_cast<const SFM_GLOBAL_AS sfm_u32x4*>(as_global(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void global_add_u32(uint32_t* p, uint32_t v) {   // no value comes back: nothing to wait for
+  __hip_atomic_fetch_add(as_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int DIM = 128;
 constexpr int GROUPS = 6;                 // bucket_group_size, cascade_hash_matcher.cc:122
 constexpr int GROUP_BITS = 10;            // bits_of_group, :123
@@ -376,9 +400,9 @@ __device__ __forceinline__ void fold_distance(const CascadePair& P, uint32_t i, 
 // The walk is bound by the bytes it streams (its two loading phases run at 6-8 TB/s), so it streams
 // as few as it can: per record of either image only the low 64 bits of the hash code, plus two
 // bytes of bucket id on the first image's side.  Two codes that differ in more than ten of those
-// 64 bits (practically every candidate) are done after two XORs and two population counts; the
-// candidates that pass are queued per wavefront and finished afterwards with every lane busy, from
-// the high halves, bucket ids and indices in memory.
+// 64 bits (practically every candidate) are done after two XORs and two population counts, four
+// candidates per step; the candidates that pass are queued for the whole workgroup and finished
+// after the chunk's scan, one per thread, from the high halves, bucket ids and indices in memory.
 // The close pairs found go to a segment of the pair's list that belongs to this workgroup alone:
 // nothing is reserved through an atomic and nothing waits for one.
 // A pair that shares buckets in several groups is handled in the lowest such group only: that is
@@ -395,62 +419,63 @@ constexpr int WALK_CHUNK = 512;      // staged records of the second image per s
 constexpr int LIST_SEGMENT = 128;    // close pairs a workgroup can report
 
 constexpr uint32_t WORK_SLOTS = 1024; // counters the statistics of a walk are spread over
-constexpr int WALK_QUEUE = 256;      // candidates per wavefront and staged chunk that pass the first test
+constexpr int WALK_STEP = 4;         // candidates a lane tests per step of the scan
+constexpr int WALK_QUEUE = 2048;     // candidates of a workgroup and staged chunk that pass the first test and wait for the second
 
 struct WalkShared {
-  uint2 lo[WALK_CHUNK + 2];     // low halves of the staged codes (+2: the scan reads in twos)
+  uint2 lo[WALK_CHUNK + WALK_STEP];   // low halves of the staged codes (the scan reads in fours, also across the end)
+  uint2 own[WALK_THREADS];            // low halves of the workgroup's own records, by thread
   uint2 found[LIST_SEGMENT];
-  uint32_t queue[WALK_THREADS / 64][WALK_QUEUE];   // per wavefront: owner lane << 16 | staged index
+  uint32_t queue[WALK_QUEUE];         // owner thread << 16 | staged index
   int range[2];
   uint32_t n_found;
+  uint32_t n_queued;
 };
 
-// Second half of the scan for the queued candidates of one wavefront: entry k goes to lane k % 64,
-// which takes the low half of the first-image code from the lane that owns the record and reads
-// the rest of both records (high halves, bucket ids, indices) from memory -- 64 candidates per
-// round trip, where a lane finishing its own on the spot would hold up its 63 neighbours.
-// a_at: position of lane 0's record in the first image's bucket order; b_at: of staged index 0.
+// Second half of the test for one candidate that passed the first: the rest of both records
+// (high halves, bucket ids, indices) from memory.
+// a_at: position of thread 0's record in the first image's bucket order; b_at: of staged index 0.
 template <int MODE>
-__device__ __forceinline__ void finish_queue(const CascadePair& P, int g, int both_directions, WalkShared& sh,
-                                             const uint32_t* queue, uint32_t count, uint2 lo, size_t a_at, size_t b_at) {
-  const int lane = threadIdx.x & 63;
-  for (uint32_t k0 = 0; k0 < count; k0 += 64) {    // count is the same in every lane
-    const uint32_t k = k0 + lane;
-    const bool mine = k < count;
-    const uint32_t entry = mine ? queue[k] : 0u;
-    const int owner = (int)(entry >> 16), r = (int)(entry & 0xFFFFu);
-    const uint32_t alx = __shfl(lo.x, owner), aly = __shfl(lo.y, owner);
-    if (!mine) continue;
-    // the bucket ids first: a pair of near-duplicates shares most of its six buckets and is dropped
-    // here in all groups but the lowest, before its codes are fetched
-    const HashMeta ma = P.a_meta[a_at + owner], other = P.b_meta[b_at + r];
-    const uint32_t x0 = ma.bids[0] ^ other.bids[0], x1 = ma.bids[1] ^ other.bids[1], x2 = ma.bids[2] ^ other.bids[2];
-    bool earlier = false;   // shares a bucket in a group before g: counted there
-    if (g > 0) earlier |= (x0 & 0xFFFFu) == 0;
-    if (g > 1) earlier |= (x0 >> 16) == 0;
-    if (g > 2) earlier |= (x1 & 0xFFFFu) == 0;
-    if (g > 3) earlier |= (x1 >> 16) == 0;
-    if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
-    if (earlier) continue;
-    const uint2 ah = P.a_hi[a_at + owner], bh = P.b_hi[b_at + r];
-    const uint2 bl = sh.lo[r];
-    const uint32_t h = __popc(alx ^ bl.x) + __popc(aly ^ bl.y) + __popc(ah.x ^ bh.x) + __popc(ah.y ^ bh.y);
-    if (h > (uint32_t)MAX_HAMMING) continue;
-    const uint32_t i = ma.idx, j = other.idx;
-    if (MODE == WALK_COUNT) {
-      atomicAdd(P.hist_a + (size_t)i * HIST_WORDS + h, 1u);
-      if (both_directions) atomicAdd(P.hist_b + (size_t)j * HIST_WORDS + h, 1u);
-      const uint32_t at = atomicAdd(&sh.n_found, 1u);
-      if (at < (uint32_t)LIST_SEGMENT) sh.found[at] = make_uint2(i, j | (h << LIST_H_SHIFT));
-    } else {
-      const bool fa = inside_taken_bins(P.res_a[(size_t)i * RES_WORDS + RES_STATE], h);
-      const bool fb = both_directions && inside_taken_bins(P.res_b[(size_t)j * RES_WORDS + RES_STATE], h);
-      if (fa || fb) fold_distance(P, i, j, fa, fb);
-    }
+__device__ __forceinline__ void finish_candidate(const CascadePair& P, int g, int both_directions, WalkShared& sh,
+                                                 uint32_t entry, size_t a_at, size_t b_at) {
+  const int owner = (int)(entry >> 16), r = (int)(entry & 0xFFFFu);
+  // Bucket ids + index and the high halves of both records, all four loads on their way at once: one
+  // trip to memory instead of two (the candidates that pass the first test are few, so the high
+  // halves fetched for the ones the bucket ids then drop cost next to nothing).
+  const uint4 ma4 = global_load(reinterpret_cast<const uint4*>(P.a_meta) + (a_at + owner));
+  const uint4 mb4 = global_load(reinterpret_cast<const uint4*>(P.b_meta) + (b_at + r));
+  uint2 ah = global_load(P.a_hi + (a_at + owner)), bh = global_load(P.b_hi + (b_at + r));
+  asm volatile("" : "+v"(ah.x), "+v"(ah.y), "+v"(bh.x), "+v"(bh.y));   // keeps the last two loads in front of the test below
+  // a pair of near-duplicates shares most of its six buckets and is counted in the lowest such group only
+  const uint32_t x0 = ma4.x ^ mb4.x, x1 = ma4.y ^ mb4.y, x2 = ma4.z ^ mb4.z;
+  bool earlier = false;   // shares a bucket in a group before g: counted there
+  if (g > 0) earlier |= (x0 & 0xFFFFu) == 0;
+  if (g > 1) earlier |= (x0 >> 16) == 0;
+  if (g > 2) earlier |= (x1 & 0xFFFFu) == 0;
+  if (g > 3) earlier |= (x1 >> 16) == 0;
+  if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
+  if (earlier) return;
+  const uint2 al = sh.own[owner], bl = sh.lo[r];
+  const uint32_t h = __popc(al.x ^ bl.x) + __popc(al.y ^ bl.y) + __popc(ah.x ^ bh.x) + __popc(ah.y ^ bh.y);
+  if (h > (uint32_t)MAX_HAMMING) return;
+  const uint32_t i = ma4.w, j = mb4.w;
+#if defined(SFM_ABLATE_WALK_UPTO) && SFM_ABLATE_WALK_UPTO == 5   // timing experiments only: finished, nothing recorded
+  if (ma4.x != 0x12345678u) return;
+#endif
+  if (MODE == WALK_COUNT) {
+    global_add_u32(P.hist_a + (size_t)i * HIST_WORDS + h, 1u);
+    if (both_directions) global_add_u32(P.hist_b + (size_t)j * HIST_WORDS + h, 1u);
+    const uint32_t at = atomicAdd(&sh.n_found, 1u);
+    if (at < (uint32_t)LIST_SEGMENT) sh.found[at] = make_uint2(i, j | (h << LIST_H_SHIFT));
+  } else {
+    const bool fa = inside_taken_bins(P.res_a[(size_t)i * RES_WORDS + RES_STATE], h);
+    const bool fb = both_directions && inside_taken_bins(P.res_b[(size_t)j * RES_WORDS + RES_STATE], h);
+    if (fa || fb) fold_distance(P, i, j, fa, fb);
   }
 }
 
 // The work of workgroup bx of nbx for (pair P, group g).
+// work (may be null): WORK_SLOTS counters that receive the number of candidates tested (statistics).
 template <int MODE>
 __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, int nbx, int both_directions,
                                            WalkShared& sh, unsigned long long* __restrict__ work = nullptr) {
@@ -477,9 +502,11 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
     s = off[b];
     e = off[b + 1];
   }
+  sh.own[tid] = lo_half;
   if (tid == 0) {
     range[0] = s;
     sh.n_found = 0;
+    sh.n_queued = 0;
   }
   if (p == min(p0 + WALK_THREADS - 1, na - 1)) range[1] = e;
   if (work) {   // statistics only: candidates this wavefront will test, into one of WORK_SLOTS counters
@@ -494,46 +521,57 @@ __device__ __forceinline__ void walk_block(const CascadePair& P, int g, int bx, 
 #else
   const int lo = range[0], hi = range[1];
 #endif
-  uint32_t* queue = sh.queue[tid >> 6];
-  const int lane = tid & 63;
-  const unsigned long long below = ((unsigned long long)1 << lane) - 1;
-  const size_t a_at = a_group + (size_t)(p0 + (tid & ~63));   // lane 0's record
+  const size_t a_at = a_group + (size_t)p0;   // thread 0's record
   for (int c0 = lo; c0 < hi; c0 += WALK_CHUNK) {
     const int cnt = min(WALK_CHUNK, hi - c0);
     for (int r = tid; r < cnt; r += WALK_THREADS) stage_lo[r] = b_lo[c0 + r];
     __syncthreads();
-    // First test, every candidate: the low 64 bits, two candidates per step.  The few that pass
-    // are queued per wavefront (ballot, no atomics) and finished afterwards with every lane busy.
+    // First test, every candidate: the low 64 bits, four candidates per step.  The few that pass are
+    // queued for the whole workgroup and finished after the scan, one per thread: a wavefront that
+    // finished its own few on the spot would spend a whole pass of 64 lanes on them, four times per
+    // workgroup.
 #if defined(SFM_ABLATE_WALK_UPTO) && SFM_ABLATE_WALK_UPTO <= 2   // timing experiments only
     const int q1 = stage_lo[tid].x == 0x12345678u ? e : 0;
 #else
     const int q1 = min(e, c0 + cnt);
 #endif
-    uint32_t queued = 0;     // the same in every lane of the wavefront
-    for (int q = max(s, c0); __any(q < q1); q += 2) {
-      const bool live = q < q1;
-      const int r = live ? q - c0 : 0;
-      const uint2 t0 = stage_lo[r], t1 = stage_lo[r + 1];
-      const bool hit0 = live && __popc(lo_half.x ^ t0.x) + __popc(lo_half.y ^ t0.y) <= (uint32_t)MAX_HAMMING;
-      const bool hit1 = live && q + 1 < q1 && __popc(lo_half.x ^ t1.x) + __popc(lo_half.y ^ t1.y) <= (uint32_t)MAX_HAMMING;
+    const size_t b_at = b_group + (size_t)c0;
+    for (int q = max(s, c0); q < q1; q += WALK_STEP) {
+      const int r = q - c0;
+      // Nothing but the four distances on the way that nearly every step takes: which of the four are
+      // real (a bucket seldom ends on a multiple of four; what lies behind it are the next bucket's
+      // codes) is only asked when one of them passes.
+      uint32_t h[WALK_STEP];
+#pragma unroll
+      for (int k = 0; k < WALK_STEP; k++) {
+        const uint2 t = stage_lo[r + k];
+        h[k] = __popc(lo_half.x ^ t.x) + __popc(lo_half.y ^ t.y);
+      }
+      const uint32_t nearest = min(min(h[0], h[1]), min(h[2], h[3]));
 #if defined(SFM_ABLATE_WALK_UPTO) && SFM_ABLATE_WALK_UPTO <= 3   // timing experiments only
-      if (!__any((hit0 || hit1) && t0.x == 0x12345678u)) continue;
+      if (nearest > (uint32_t)MAX_HAMMING || lo_half.x != 0x12345678u) continue;
 #else
-      if (!__any(hit0 || hit1)) continue;
+      if (nearest > (uint32_t)MAX_HAMMING) continue;
 #endif
-      const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-      const uint32_t at0 = queued + __popcll(m0 & below);
-      const uint32_t at1 = queued + __popcll(m0) + __popcll(m1 & below);
-      if (hit0) queue[at0] = ((uint32_t)lane << 16) | (uint32_t)r;
-      if (hit1) queue[at1] = ((uint32_t)lane << 16) | (uint32_t)(r + 1);
-      queued += __popcll(m0) + __popcll(m1);
-      if (queued > (uint32_t)WALK_QUEUE - 128) {     // the next step might not fit: finish these now
-        finish_queue<MODE>(P, g, both_directions, sh, queue, queued, lo_half, a_at, b_group + (size_t)c0);
-        queued = 0;
+#pragma unroll
+      for (int k = 0; k < WALK_STEP; k++) {
+        if (q + k < q1 && h[k] <= (uint32_t)MAX_HAMMING) {
+          const uint32_t entry = ((uint32_t)tid << 16) | (uint32_t)(r + k);
+          const uint32_t at = atomicAdd(&sh.n_queued, 1u);
+          if (at < (uint32_t)WALK_QUEUE) sh.queue[at] = entry;
+          else finish_candidate<MODE>(P, g, both_directions, sh, entry, a_at, b_at);   // no room (images full of near-identical descriptors): on the spot
+        }
       }
     }
-    finish_queue<MODE>(P, g, both_directions, sh, queue, queued, lo_half, a_at, b_group + (size_t)c0);
     __syncthreads();
+#if defined(SFM_ABLATE_WALK_UPTO) && SFM_ABLATE_WALK_UPTO == 4   // timing experiments only: candidates queued, none finished
+    const uint32_t queued = lo_half.x == 0x12345678u ? min(sh.n_queued, (uint32_t)WALK_QUEUE) : 0u;
+#else
+    const uint32_t queued = min(sh.n_queued, (uint32_t)WALK_QUEUE);
+#endif
+    for (uint32_t k = tid; k < queued; k += WALK_THREADS) finish_candidate<MODE>(P, g, both_directions, sh, sh.queue[k], a_at, b_at);
+    __syncthreads();
+    if (tid == 0) sh.n_queued = 0;   // the next appends come after the next chunk's barrier
   }
   if (MODE == WALK_COUNT) {
     // no round trip here: the segment is this workgroup's own

@@ -21,7 +21,10 @@ constexpr int MAX_PAIRS_PER_BATCH = 1024;
 constexpr size_t SLOT_BYTES_PER_BATCH = (size_t)2 << 30;
 constexpr size_t LIST_BYTES_PER_BATCH = (size_t)1 << 30;
 
-constexpr int NEAREST_BLOCKS = 8;    // workgroups striding one pair's list
+#ifndef SFM_NEAREST_BLOCKS   // (overridden in timing experiments: tools/build_variant.sh)
+#define SFM_NEAREST_BLOCKS 8
+#endif
+constexpr int NEAREST_BLOCKS = SFM_NEAREST_BLOCKS;    // workgroups striding one pair's list
 constexpr int FALLBACK_BLOCKS = 8;   // workgroups striding one pair's queries / records on the list-free path
 
 // Workgroups per (pair, group) of the bucket walk: one per 256 records of the largest first image
