@@ -40,13 +40,24 @@ constexpr uint32_t SENT = 0xFFFFFFFFu;   // "empty" key, larger than every real 
 // mantissa bits replaced by a local index.  Rounding can leave a distance that is really ~0 slightly
 // negative; clearing the sign turns it into an equally tiny positive key, so it still sorts first
 // and unsigned integer order equals numeric order for every key.
-constexpr int ROW_IDX_BITS = 9;      // row lists: low bits = 32-column tile number inside the chunk
-constexpr uint32_t ROW_LOW = (1u << ROW_IDX_BITS) - 1u;
-constexpr uint32_t ROW_MASK = 0x7FFFFFFFu & ~ROW_LOW;
-constexpr int MAX_CHUNK_COLS = 32 << ROW_IDX_BITS;   // 16384
-constexpr int COL_IDX_BITS = 8;      // column lists: low bits = row inside the 256-row block (permuted)
-constexpr uint32_t COL_LOW = (1u << COL_IDX_BITS) - 1u;
-constexpr uint32_t COL_MASK = 0x7FFFFFFFu & ~COL_LOW;
+// One key per accumulator element serves the element's row list and its column list, so its low
+// bits name both the column tile (for the row list: the lane is the column inside the tile) and
+// the row (for the column list): one v_and_or_b32 per element whose OR operand is a scalar that
+// changes per tile and register, built on the scalar unit beside the matrix instructions.  Eight
+// value bits of the mantissa remain, which is plenty for lists whose only job is to keep the two
+// smallest of a lane's entries and a bound on the rest (the re-rank's intervals widen with them).
+//   bits 0..3   accumulator register   } the row inside the 256-row block, permuted: col_key_row();
+//   bit  4      half-wave              } bits 4, 6 and 7 are the same for all of a lane's elements and
+//   bit  5      row tile of the wave   } are put in when a column list is parked (the tile number,
+//   bits 6..7   wave                   } of no use to a column list, goes out at the same time)
+//   bits 6..14  32-column tile number inside the chunk (row lists)
+constexpr int KEY_IDX_BITS = 15;
+constexpr uint32_t KEY_LOW = (1u << KEY_IDX_BITS) - 1u;
+constexpr uint32_t KEY_MASK = 0x7FFFFFFFu & ~KEY_LOW;    // the value bits of a key
+constexpr int KEY_TILE_SHIFT = 6, KEY_TILE_BITS = 9;
+constexpr uint32_t KEY_TILE_FIELD = ((1u << KEY_TILE_BITS) - 1u) << KEY_TILE_SHIFT;
+constexpr int MAX_CHUNK_COLS = 32 << KEY_TILE_BITS;   // 16384
+constexpr uint32_t COL_LOW = 0xFFu;  // parked column keys: the row inside the 256-row block (permuted)
 constexpr float PAD_NORM = 1e30f;    // squared norm given to padding rows: never a near neighbour
 // Keys (and with them every bound the re-rank derives from keys) mean something only while all real
 // rows of both images have squared norms below this: from PAD_NORM on the distance kernel gives a
@@ -253,8 +264,8 @@ __global__ __launch_bounds__(256) void k_split(const float* __restrict__ x, cons
 // 2-entry list per row over the columns it sees (c, c+32, ...) and the lists are
 // merged once, at the end of the chunk.  Two entries, not three: a list's second entry is
 // also the bound on what the list dropped, and that is all the re-rank needs from it (it
-// decides nearly every query from the two smallest keys and a bound) -- six vector
-// instructions per accumulator element instead of eight.  The price: a query whose two
+// decides nearly every query from the two smallest keys and a bound), and one key serves an
+// element's row list and its column list -- five vector instructions per accumulator element.  The price: a query whose two
 // nearest columns share a list AND whose ratio test is too close for the keys to call
 // cannot be proven complete from the lists and takes the exact full scan.
 // ---------------------------------------------------------------------------
@@ -324,6 +335,8 @@ __device__ __forceinline__ void lds_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+constexpr uint32_t COL_PARK_MASK = ~KEY_TILE_FIELD;   // a column key as it is parked: without the tile number
+
 // Private row lists of one lane for one 32-row tile: per accumulator register (= row)
 // the two smallest keys over the columns this lane has seen.  The second one doubles as the bound
 // on everything the lane saw and did not keep.
@@ -363,10 +376,16 @@ struct StageFeed {
   int w;
 };
 
+// The index bits of the keys of a tile pair's 32 accumulator registers (element E: register E & 15
+// of row tile E >> 4), each a scalar register of its own.
+struct KeyIndex {
+  uint32_t c[32];
+};
+
 template <int ENGINE, int TOFF, int S, int ROT, bool HAS_NEXT, int PIECE>
 __device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const f32x4 (&a0)[16], const f32x4 (&a1)[16],
                                           f32x4 (&b)[NFRAG], const uint32_t (&X)[8], const StageFeed& feed,
-                                          const uint32_t (&yvoff)[8]) {
+                                          const uint32_t (&yvoff)[8], uint32_t tile6, KeyIndex& kx) {
   if constexpr (S + 2 < 16) {
     lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(S + 2 + ROT) % NFRAG], X[(S + 2) & 7]);
     lds_wait<2>();
@@ -401,6 +420,15 @@ __device__ __forceinline__ void pair_step(f32x16& acc0, f32x16& acc1, const f32x
 #ifndef SFM_ABLATE_GLDS
   if constexpr (PIECE >= 0) stage_load_piece<PIECE>(feed.src, feed.ldsbuf, feed.w, yvoff, feed.sbase);
 #endif
+  if constexpr (ENGINE == ENGINE_F32) {
+    // two of the tile pair's key constants per step: scalar additions, which cost nothing beside the
+    // matrix instructions (in the fold they would take a vector instruction's turn each)
+#pragma unroll
+    for (int e = 2 * S; e < 2 * S + 2; e++) {
+      kx.c[e] = tile6 + (uint32_t)((e >> 4) * 32 + (e & 15));
+      asm volatile("" : "+s"(kx.c[e]));   // a scalar register, and the sum as it is (not tile6 | low bits at the point of use)
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -415,21 +443,25 @@ template <int ENGINE, int TOFF, int ROT, bool HAS_NEXT, int CT, int... S>
 __device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32x16& acc0, f32x16& acc1,
                                            const f32x4 (&a0)[16], const f32x4 (&a1)[16], f32x4 (&b)[NFRAG],
                                            const uint32_t (&X)[8], const StageFeed& feed,
-                                           const uint32_t (&yvoff)[8]) {
+                                           const uint32_t (&yvoff)[8], uint32_t tile6, KeyIndex& kx) {
   // piece 4 CT + S/4 of the next stage leaves with step S = 1, 5, 9, 13 of column tile CT
-  (pair_step<ENGINE, TOFF, S, ROT, HAS_NEXT, SFM_PIECE_AT(CT, S)>(acc0, acc1, a0, a1, b, X, feed, yvoff),
+  (pair_step<ENGINE, TOFF, S, ROT, HAS_NEXT, SFM_PIECE_AT(CT, S)>(acc0, acc1, a0, a1, b, X, feed, yvoff, tile6, kx),
    ...);
 }
 
-// Fold one finished accumulator tile into the lane's row lists and column list.
-// tv = column-tile number (row key low bits); RT = which of the wave's two row tiles.
+// Fold one finished accumulator tile into the lane's row lists and column list: five vector
+// instructions per element (the key, two for either list).
+// kx = the index bits of the tile pair's keys (column-tile number << KEY_TILE_SHIFT, + RT * 32 + reg),
+// one scalar per element, built beside the matrix instructions; RT = which of the wave's two row tiles.
 template <int RT>
-__device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLists& L, uint32_t& cl0, uint32_t& cl1) {
+__device__ __forceinline__ void tile_fold(const f32x16& acc, const KeyIndex& kx, uint32_t vmask, LaneLists& L, uint32_t& cl0,
+                                          uint32_t& cl1) {
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
     const uint32_t gb = __float_as_uint(acc[reg]);
-    insert2(L.r0[reg], L.r1[reg], (gb & ROW_MASK) | tv);
-    insert2(cl0, cl1, (gb & COL_MASK) | (uint32_t)(RT * 32 + reg));
+    const uint32_t key = (gb & vmask) | kx.c[RT * 16 + reg];
+    insert2(L.r0[reg], L.r1[reg], key);
+    insert2(cl0, cl1, key);
   }
 }
 
@@ -445,8 +477,8 @@ __device__ __forceinline__ void tile_fold(const f32x16& acc, uint32_t tv, LaneLi
 #endif
 template <int ENGINE, int CT>
 __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
-                                          f32x4 (&b)[NFRAG], const uint32_t (&X)[8], uint32_t tv, LaneLists& L0,
-                                          LaneLists& L1, uint32_t lowc, int h, uint32_t* cb, const StageFeed& feed,
+                                          f32x4 (&b)[NFRAG], const uint32_t (&X)[8], uint32_t tile6, uint32_t vmask,
+                                          LaneLists& L0, LaneLists& L1, uint32_t lowc, int h, uint32_t* cb, const StageFeed& feed,
                                           const uint32_t (&yvoff)[8] SFM_FOLD_CYCLES_PARAM) {
   constexpr int TOFF = CT * 32 * DIM * 4;
 #ifdef SFM_K1_STAMPS
@@ -461,8 +493,9 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
   for (int i = 0; i < 16; i++) zero[i] = 0.0f;
   f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
   f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
+  KeyIndex kx;
   pair_steps<ENGINE, TOFF, (16 * CT) % NFRAG, (CT < 3), CT>(std::make_integer_sequence<int, 16>{}, acc0, acc1, a0, a1, b, X, feed,
-                                                 yvoff);
+                                                 yvoff, tile6, kx);
 
   uint32_t cl0 = SENT, cl1 = SENT;
 #ifdef SFM_ABLATE_FOLD
@@ -474,8 +507,8 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
   g_fold_cycles += (tf0 - tm0) << 32;   // high half: the matrix section of the tile pair
   __builtin_amdgcn_sched_barrier(0);
 #endif
-  tile_fold<0>(acc0, tv, L0, cl0, cl1);
-  tile_fold<1>(acc1, tv, L1, cl0, cl1);
+  tile_fold<0>(acc0, kx, vmask, L0, cl0, cl1);
+  tile_fold<1>(acc1, kx, vmask, L1, cl0, cl1);
 #ifdef SFM_K1_STAMPS
   anchor16(L0.r0); anchor16(L0.r1);
   anchor16(L1.r0); anchor16(L1.r1);
@@ -487,8 +520,9 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
 #endif
   // every lane parks its list (over its half-wave's 32 rows of the column); the eight lists of a
   // column -- four waves, two half-waves -- are merged once per stage
-  cb[0] = cl0 | lowc;
-  cb[64] = cl1 | lowc;
+  // (the tile number goes out, the lane's part of the row comes in: COL_PARK_MASK)
+  cb[0] = (cl0 & COL_PARK_MASK) | lowc;
+  cb[64] = (cl1 & COL_PARK_MASK) | lowc;
   // keep the epilogue where it is written: next to this tile pair, not sunk to the end of the stage
   anchor16(L0.r0); anchor16(L0.r1);
   anchor16(L1.r0); anchor16(L1.r1);
@@ -509,25 +543,26 @@ struct FoldState {
 
 // Element E of a finished tile pair: E < 16 is register E of the first row tile's accumulator.
 template <int E>
-__device__ __forceinline__ void fold_elem(const f32x16& p0, const f32x16& p1, uint32_t tv, LaneLists& L0, LaneLists& L1,
-                                          FoldState& f) {
+__device__ __forceinline__ void fold_elem(const f32x16& p0, const f32x16& p1, uint32_t tile6, uint32_t vmask, LaneLists& L0,
+                                          LaneLists& L1, FoldState& f) {
   constexpr int RT = E >> 4, REG = E & 15;
   const uint32_t gb = __float_as_uint(RT == 0 ? p0[REG] : p1[REG]);
   LaneLists& L = RT == 0 ? L0 : L1;
-  insert2(L.r0[REG], L.r1[REG], (gb & ROW_MASK) | tv);
-  insert2(f.cl0, f.cl1, (gb & COL_MASK) | (uint32_t)(RT * 32 + REG));
+  const uint32_t key = (gb & vmask) | (tile6 + (uint32_t)(RT * 32 + REG));
+  insert2(L.r0[REG], L.r1[REG], key);
+  insert2(f.cl0, f.cl1, key);
 }
 template <int... E>
 __device__ __forceinline__ void fold_elems(std::integer_sequence<int, E...>, const f32x16& p0, const f32x16& p1,
-                                           uint32_t tv, LaneLists& L0, LaneLists& L1, FoldState& f) {
-  (fold_elem<E>(p0, p1, tv, L0, L1, f), ...);
+                                           uint32_t tile6, uint32_t vmask, LaneLists& L0, LaneLists& L1, FoldState& f) {
+  (fold_elem<E>(p0, p1, tile6, vmask, L0, L1, f), ...);
 }
 
 template <int CT, int S, bool FOLD, bool HAS_NEXT, int PIECE>
 __device__ __forceinline__ void pipe_step(f32x16& acc0, f32x16& acc1, const f32x4 (&a0)[16], const f32x4 (&a1)[16],
                                           f32x4 (&b)[NFRAG], const uint32_t (&X)[8], const StageFeed& feed,
                                           const uint32_t (&yvoff)[8], const f32x16& p0, const f32x16& p1, uint32_t tvp,
-                                          LaneLists& L0, LaneLists& L1, FoldState& f) {
+                                          uint32_t vmask, LaneLists& L0, LaneLists& L1, FoldState& f) {
   constexpr int TOFF = CT * 32 * DIM * 4;
   if constexpr (S + 2 < 16) {
     lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(16 * CT + S + 2) % NFRAG], X[(S + 2) & 7]);
@@ -543,16 +578,16 @@ __device__ __forceinline__ void pipe_step(f32x16& acc0, f32x16& acc1, const f32x
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S]), frag, acc1, 0, 0, 0);
     if constexpr (FOLD) {
-      fold_elem<4 * (S / 2)>(p0, p1, tvp, L0, L1, f);
-      fold_elem<4 * (S / 2) + 1>(p0, p1, tvp, L0, L1, f);
+      fold_elem<4 * (S / 2)>(p0, p1, tvp, vmask, L0, L1, f);
+      fold_elem<4 * (S / 2) + 1>(p0, p1, tvp, vmask, L0, L1, f);
     }
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S + 1]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S + 1]), frag, acc1, 0, 0, 0);
-    if constexpr (FOLD) fold_elem<4 * (S / 2) + 2>(p0, p1, tvp, L0, L1, f);
+    if constexpr (FOLD) fold_elem<4 * (S / 2) + 2>(p0, p1, tvp, vmask, L0, L1, f);
   } else {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S - 1]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S - 1]), frag, acc1, 0, 0, 0);
-    if constexpr (FOLD) fold_elem<4 * (S / 2) + 3>(p0, p1, tvp, L0, L1, f);
+    if constexpr (FOLD) fold_elem<4 * (S / 2) + 3>(p0, p1, tvp, vmask, L0, L1, f);
   }
 #ifndef SFM_ABLATE_GLDS
   if constexpr (PIECE >= 0) stage_load_piece<PIECE>(feed.src, feed.ldsbuf, feed.w, yvoff, feed.sbase);
@@ -567,7 +602,7 @@ __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x
                                           const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
                                           f32x4 (&b)[NFRAG], const uint32_t (&X)[8], const StageFeed& feed,
                                           const uint32_t (&yvoff)[8], const f32x16& p0, const f32x16& p1, uint32_t tvp,
-                                          LaneLists& L0, LaneLists& L1, uint32_t lowc, uint32_t* cbp) {
+                                          uint32_t vmask, LaneLists& L0, LaneLists& L1, uint32_t lowc, uint32_t* cbp) {
   if constexpr (CT == 0) {
     lds_read16<0>(b[0], X[0]);
     lds_read16<0>(b[1], X[1]);
@@ -579,12 +614,12 @@ __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x
   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
   FoldState f{SENT, SENT};
   (pipe_step<CT, S, FOLD, (CT < 3), SFM_PIECE_AT(CT, S)>(acc0, acc1, a0, a1, b, X, feed, yvoff, p0, p1, tvp,
-                                                                        L0, L1, f),
+                                                                        vmask, L0, L1, f),
    ...);
   if constexpr (FOLD) {
     // all thirty-two elements went in beside the matrix instructions: the tile's column lists are complete
-    cbp[0] = f.cl0 | lowc;
-    cbp[64] = f.cl1 | lowc;
+    cbp[0] = (f.cl0 & COL_PARK_MASK) | lowc;
+    cbp[64] = (f.cl1 & COL_PARK_MASK) | lowc;
   }
 }
 
@@ -835,8 +870,12 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     if (gg >= 1)
       stage_columns_out(colbuf_addr + (u ^ 1) * LDS_COLBUF_WORDS * 4, h, coldst, colvoff, (uint32_t)((gg - 1) * SN * 4),
                         plane_bytes);
-    uint32_t tv = (uint32_t)(4 * gg);
-    asm volatile("" : "+v"(tv));   // a VGPR, so that the row key is one v_and_or_b32
+    // tile number of the stage's first column tile, in its place inside a key; the same in every lane
+    const uint32_t tv = (uint32_t)(4 * gg) << KEY_TILE_SHIFT;
+    constexpr uint32_t T1 = 1u << KEY_TILE_SHIFT;
+    uint32_t vmask = KEY_MASK;
+    asm volatile("" : "+v"(vmask));   // a VGPR: the key's other operands are the accumulator and a scalar, and an
+                                      // instruction takes one scalar at most
     uint32_t* cb = colbuf + u * LDS_COLBUF_WORDS + (w * 4 * 2) * 64 + l;
     if constexpr (ENGINE == ENGINE_F32) {
 #ifdef SFM_K1_STAMPS
@@ -844,22 +883,22 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
       stamp_head += __builtin_amdgcn_s_memtime() - th0;
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0, L0, L1, lowc, h, cb + 0 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
-      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1, L0, L1, lowc, h, cb + 1 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
-      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2, L0, L1, lowc, h, cb + 2 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
-      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3, L0, L1, lowc, h, cb + 3 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0 * T1, vmask, L0, L1, lowc, h, cb + 0 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1 * T1, vmask, L0, L1, lowc, h, cb + 1 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2 * T1, vmask, L0, L1, lowc, h, cb + 2 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3 * T1, vmask, L0, L1, lowc, h, cb + 3 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
     } else {
       constexpr auto STEPS = std::make_integer_sequence<int, 16>{};
       f32x16 e0, e1, o0, o1;   // accumulators of the even and of the odd column tiles
-      pipe_tile<0, false>(STEPS, e0, e1, a0, a1, an0, an1, bn[0], b, X, feed, yvoff, o0, o1, tv, L0, L1, lowc, cb);
-      pipe_tile<1, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[1], b, X, feed, yvoff, e0, e1, tv + 0, L0, L1, lowc, cb + 0 * 128);
-      pipe_tile<2, true>(STEPS, e0, e1, a0, a1, an0, an1, bn[2], b, X, feed, yvoff, o0, o1, tv + 1, L0, L1, lowc, cb + 1 * 128);
-      pipe_tile<3, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[3], b, X, feed, yvoff, e0, e1, tv + 2, L0, L1, lowc, cb + 2 * 128);
+      pipe_tile<0, false>(STEPS, e0, e1, a0, a1, an0, an1, bn[0], b, X, feed, yvoff, o0, o1, tv, vmask, L0, L1, lowc, cb);
+      pipe_tile<1, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[1], b, X, feed, yvoff, e0, e1, tv + 0 * T1, vmask, L0, L1, lowc, cb + 0 * 128);
+      pipe_tile<2, true>(STEPS, e0, e1, a0, a1, an0, an1, bn[2], b, X, feed, yvoff, o0, o1, tv + 1 * T1, vmask, L0, L1, lowc, cb + 1 * 128);
+      pipe_tile<3, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[3], b, X, feed, yvoff, e0, e1, tv + 2 * T1, vmask, L0, L1, lowc, cb + 2 * 128);
       // the stage's last tile has no matrix work left to hide behind
       FoldState f{SENT, SENT};
-      fold_elems(std::make_integer_sequence<int, 32>{}, o0, o1, tv + 3, L0, L1, f);
-      cb[3 * 128 + 0] = f.cl0 | lowc;
-      cb[3 * 128 + 64] = f.cl1 | lowc;
+      fold_elems(std::make_integer_sequence<int, 32>{}, o0, o1, tv + 3 * T1, vmask, L0, L1, f);
+      cb[3 * 128 + 0] = (f.cl0 & COL_PARK_MASK) | lowc;
+      cb[3 * 128 + 64] = (f.cl1 & COL_PARK_MASK) | lowc;
       anchor16(L0.r0); anchor16(L0.r1);
       anchor16(L1.r0); anchor16(L1.r1);
     }
@@ -922,13 +961,13 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     uint32_t lanebound = SENT;
 #pragma unroll 8
     for (int p = 0; p < 32; p++) {
-      put((src[p * 2] & ROW_MASK) | (uint32_t)p);
+      put((src[p * 2] & KEY_MASK) | (uint32_t)p);
       const uint32_t k1 = src[p * 2 + 1];
       lanebound = lanebound < k1 ? lanebound : k1;
     }
     const uint32_t hp[5] = {m0 & 31u, m1 & 31u, m2 & 31u, m3 & 31u, m4 & 31u};
 #pragma unroll
-    for (int e = 0; e < 5; e++) put((src[hp[e] * 2 + 1] & ROW_MASK) | hp[e] | 32u);
+    for (int e = 0; e < 5; e++) put((src[hp[e] * 2 + 1] & KEY_MASK) | hp[e] | 32u);
     // low bits of a ranked key: lane (5 bits), entry in that lane's pair (1 bit)
     const uint32_t mk[4] = {m0, m1, m2, m3};
     uint32_t fullkey[4], lane[4];
@@ -937,7 +976,7 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
       lane[e] = mk[e] & 31u;
       fullkey[e] = src[lane[e] * 2 + ((mk[e] >> 5) & 1u)];
     }
-    const uint32_t fifth = m4 == SENT ? SENT : (m4 & ROW_MASK);   // value bits only: never above the real key
+    const uint32_t fifth = m4 == SENT ? SENT : (m4 & KEY_MASK);   // value bits only: never above the real key
     const uint32_t bound = lanebound < fifth ? lanebound : fifth;
     uint32_t* dst = P.rowpart + (size_t)blk.chunk * ROWPART_FIELDS * P.na_pad + blk.row0 + tid;
     const size_t st = (size_t)P.na_pad;
@@ -945,7 +984,7 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       dst[e * st] = fullkey[e];
-      dst[(4 + e) * st] = c0 + ((fullkey[e] & ROW_LOW) << 5) + lane[e];
+      dst[(4 + e) * st] = c0 + (((fullkey[e] & KEY_TILE_FIELD) >> KEY_TILE_SHIFT) << 5) + lane[e];
     }
     dst[8 * st] = bound;
   }
@@ -1063,13 +1102,15 @@ __device__ __forceinline__ double excluded_lower_bound_split(uint32_t boundkey, 
 }
 
 // The other side of the same analysis: an upper bound on the reference's squared sum of the column
-// a key belongs to.  The key's value bits v satisfy |g| < v (1 + 2^-14) (at most 9 low mantissa
+// a key belongs to.  The key's value bits v satisfy |g| < v (1 + 2^-8) (the 15 low mantissa
 // bits were replaced), t <= |g| (1 + u) + E with the same absolute error term E as above, and the
 // reference's sum is at most t (1 + 160u).
+constexpr double KEY_SLACK = 3.95e-3;   // a little over 2^-(23 - KEY_IDX_BITS)
+static_assert(KEY_IDX_BITS == 15, "KEY_SLACK goes with the number of mantissa bits a key keeps");
 __device__ __forceinline__ double key_upper_bound(uint32_t key, uint32_t mask, float nq, float nomax) {
   const double u = 5.9604644775390625e-8;
   const double v = (double)__uint_as_float(key & mask);
-  return v * (1.0 + 6.2e-5 + 400.0 * u) + 460.0 * u * ((double)nq + (double)nomax);
+  return v * (1.0 + KEY_SLACK + 400.0 * u) + 460.0 * u * ((double)nq + (double)nomax);
 }
 __device__ __forceinline__ double key_upper_bound_split(uint32_t key, uint32_t mask, float nq, float nomax, float sq,
                                                         float so) {
@@ -1078,7 +1119,7 @@ __device__ __forceinline__ double key_upper_bound_split(uint32_t key, uint32_t m
   const double v = (double)__uint_as_float(key & mask);
   const double floor_term = 2.0 * 6.103515625e-5 * 11.32 *
                             (sqrt((double)nq) * (double)sq + sqrt((double)nomax) * (double)so);
-  return (v * (1.0 + 6.2e-5 + 400.0 * u) + 1120.0 * u * sigma * ((double)nq + (double)nomax) + floor_term * 1.001) /
+  return (v * (1.0 + KEY_SLACK + 400.0 * u) + 1120.0 * u * sigma * ((double)nq + (double)nomax) + floor_term * 1.001) /
          sigma;
 }
 
@@ -1254,7 +1295,7 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
       //   column 0 <= hi_0 and everything else >= min(lo_1, lx):
       //       sqrt(hi_0) < ratio * sqrt(min(lo_1, lx))   =>  column 0 is the nearest and passes.
       // Square roots are taken of floats rounded outwards (sqrtf is monotone), in double as the rule.
-      const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
+      const uint32_t mask = KEY_MASK;
       const uint32_t xkey = lbound < a2 ? lbound : a2;
       double lo0, lo1, hi0, hi1, lx;
       if (engine == ENGINE_F32) {
@@ -1384,7 +1425,7 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
       int md = RR_FULL;
       if (provable && q < nq && c0 != SENT && c1 != SENT && c2 != SENT && c3 != SENT && bound != SENT && ratio > 0.0 &&
           ratio <= 1.0) {
-        const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
+        const uint32_t mask = KEY_MASK;
         const float nqv = qn_early;
         double lo0, lo1, hi0, hi1, lx;
         if (engine == ENGINE_F32) {
@@ -1543,7 +1584,7 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
     const uint32_t bound = bnd[tid];
     bool safe = provable && (no <= NCAND || bound == SENT);
     if (provable && !safe) {
-      const uint32_t mask = dir == 0 ? ROW_MASK : COL_MASK;
+      const uint32_t mask = KEY_MASK;
       if (engine == ENGINE_F32) {
         safe = (double)t.r2 <= excluded_lower_bound(bound, mask, my_qn, other_max);
       } else {
