@@ -138,6 +138,13 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
   return umin32(umax32(a, b), umax32(umin32(a, b), c));
 }
 
+// Smallest of three, as one instruction (the compiler does not always form it from two minima).
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 // Insert x into the ascending triple (a <= b <= c), dropping the largest of the four.
 __device__ __forceinline__ void insert3(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t x) {
   c = med3u(b, c, x);
@@ -453,16 +460,27 @@ __device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32
 // instructions per element (the key, two for either list).
 // kx = the index bits of the tile pair's keys (column-tile number << KEY_TILE_SHIFT, + RT * 32 + reg),
 // one scalar per element, built beside the matrix instructions; RT = which of the wave's two row tiles.
+// The column list takes its keys three at a time: the two smallest of three are one v_min3 and one
+// v_med3, and merging a sorted pair into a sorted pair takes three more -- five instructions where
+// three single insertions take six.
 template <int RT>
 __device__ __forceinline__ void tile_fold(const f32x16& acc, const KeyIndex& kx, uint32_t vmask, LaneLists& L, uint32_t& cl0,
                                           uint32_t& cl1) {
+  uint32_t key[16];
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
-    const uint32_t gb = __float_as_uint(acc[reg]);
-    const uint32_t key = (gb & vmask) | kx.c[RT * 16 + reg];
-    insert2(L.r0[reg], L.r1[reg], key);
-    insert2(cl0, cl1, key);
+    key[reg] = (__float_as_uint(acc[reg]) & vmask) | kx.c[RT * 16 + reg];
+    insert2(L.r0[reg], L.r1[reg], key[reg]);
   }
+#pragma unroll
+  for (int g = 0; g < 15; g += 3) {
+    const uint32_t m = min3u(key[g], key[g + 1], key[g + 2]);
+    const uint32_t s = med3u(key[g], key[g + 1], key[g + 2]);
+    const uint32_t t = umax32(cl0, m);
+    cl0 = umin32(cl0, m);
+    cl1 = min3u(t, cl1, s);   // second smallest of {cl0 <= cl1, m <= s}: min(max(cl0, m), min(cl1, s))
+  }
+  insert2(cl0, cl1, key[15]);
 }
 
 // One column tile (32 columns) against the wave's 64 rows: 2 x 65 MFMAs, then the vector
