@@ -896,7 +896,7 @@ def main():
             "pairs_per_s_this_gpu_without_kernel_timing": free_rate,
             "roofline": roofline(st, args.engine, traffic),
         }
-        if traffic is not None:
+        if traffic is not None and line["roofline"] is not None:
             line["roofline"]["traffic_source"] = "profiles/distance_kernel_traffic.json (separate counter run)"
         if not args.no_other_engine:
             # the library's other distance engine on the same steps (its own timed region)
