@@ -373,7 +373,7 @@ class SetJob:
                 t_up = time.perf_counter()
                 for i in np.unique(p).tolist():
                     if i not in resident:
-                        m.upload(i, self.images[i])
+                        m.upload_async(i, self.images[i])   # the call below waits for them; they overlap each other
                         resident.add(i)
                 self.upload_seconds += time.perf_counter() - t_up
             # queued behind call b - 1; no distances, as the C++ matcher class calls it (a Match record has none)

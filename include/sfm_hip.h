@@ -73,6 +73,16 @@ const char* sfm_hip_last_error(const sfm_hip_ctx* ctx);
  * replaces the previous data.  n may be 0.  Blocking. */
 int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n);
 
+/* The same without waiting for the copy and the preparation to finish: the call returns once they
+ * are queued on the context's upload stream, so that consecutive uploads overlap (the copy of one
+ * image runs beside the norm and split kernels of the one before) and the host goes on.  The first
+ * later call that lets the GPU read images (sfm_hip_match_pairs, sfm_hip_match_pair_noalloc,
+ * sfm_hip_cascade_*, sfm_hip_sync, a drop or replacement of an image) waits on the host until all
+ * queued uploads are complete; work queued earlier keeps the GPU busy meanwhile.  `descriptors` must
+ * stay valid and unchanged until then.  Stands in for the same copies of the reference as
+ * sfm_hip_upload_image (brute_force_matcher.cc:47-52). */
+int sfm_hip_upload_image_async(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n);
+
 /* The same, from descriptors that already lie in the memory of the context's device (for a
  * descriptor set that reached the GPU over xGMI from another GPU instead of from the host; the
  * reference has no counterpart: its images only ever live in host memory).  The source must not be

@@ -12,7 +12,7 @@ ENGINES = {"f32": 0, "f16x3": 1}
 
 EXPORTS = (
     "sfm_hip_device_count", "sfm_hip_ctx_create", "sfm_hip_ctx_destroy", "sfm_hip_last_error",
-    "sfm_hip_upload_image", "sfm_hip_drop_image", "sfm_hip_drop_all_images", "sfm_hip_image_size",
+    "sfm_hip_upload_image", "sfm_hip_upload_image_async", "sfm_hip_drop_image", "sfm_hip_drop_all_images", "sfm_hip_image_size",
     "sfm_hip_match_pairs", "sfm_hip_sync", "sfm_hip_host_alloc", "sfm_hip_host_free",
     "sfm_hip_set_profiling", "sfm_hip_get_stats", "sfm_hip_reset_stats", "sfm_hip_set_engine",
     "sfm_hip_upload_image_device", "sfm_hip_match_pair_noalloc", "sfm_hip_partition_pairs",
@@ -85,6 +85,7 @@ def library():
     lib.sfm_hip_last_error.argtypes = [vp]
     lib.sfm_hip_last_error.restype = ctypes.c_char_p
     lib.sfm_hip_upload_image.argtypes = [vp, i64, vp, i32]
+    lib.sfm_hip_upload_image_async.argtypes = [vp, i64, vp, i32]
     lib.sfm_hip_upload_image_device.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int32]
     lib.sfm_hip_drop_image.argtypes = [vp, i64]
     lib.sfm_hip_drop_all_images.argtypes = [vp]
@@ -245,6 +246,18 @@ class Matcher:
         self._check(self._lib.sfm_hip_upload_image(self._h, int(image_id), d.ctypes.data, d.shape[0]),
                     "sfm_hip_upload_image")
 
+    def upload_async(self, image_id, descriptors):
+        """sfm_hip_upload_image_async: queued, not waited for.  The array is kept alive here until the
+        next sync()."""
+        d = np.ascontiguousarray(descriptors, dtype=np.float32)
+        if d.ndim != 2 or d.shape[1] != 128:
+            raise ValueError("descriptors must be [n, 128]")
+        self._check(self._lib.sfm_hip_upload_image_async(self._h, int(image_id), d.ctypes.data, d.shape[0]),
+                    "sfm_hip_upload_image_async")
+        if not hasattr(self, "_in_flight"):
+            self._in_flight = []
+        self._in_flight.append(d)
+
     def upload_device(self, image_id, device_ptr, n):
         """Register n descriptors (rows of 128 floats) that already lie in this GPU's memory."""
         self._check(self._lib.sfm_hip_upload_image_device(self._h, int(image_id), int(device_ptr), int(n)),
@@ -295,6 +308,7 @@ class Matcher:
 
     def sync(self):
         self._check(self._lib.sfm_hip_sync(self._h), "sfm_hip_sync")
+        self._in_flight = []
 
     def wait_outputs(self, array):
         """Wait until no queued call still has to write `array` (a pinned output array, or a view of

@@ -122,6 +122,7 @@ struct sfm_hip_ctx {
   sfm_hip_stats stats{};
 
   hipStream_t upload_stream = nullptr;
+  int uploads_pending = 0;                     // sfm_hip_upload_image_async calls whose work the host has not seen finish
   int n_cu = 256;                              // compute units of the device (one distance workgroup each)
   size_t batch_bytes_limit = (size_t)6 << 30;  // work space per batch
   int max_pairs_per_batch = 256;
@@ -171,7 +172,19 @@ inline bool lane_writes(const Lane& l, const char* lo, const char* hi) {
   return false;
 }
 
+// Images handed over by sfm_hip_upload_image_async are complete: every entry point that lets a
+// kernel on another stream read an image calls this first (the host waits, the GPU keeps working on
+// what was queued before).
+inline int finish_uploads(sfm_hip_ctx* ctx) {
+  if (ctx->uploads_pending > 0) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));
+    ctx->uploads_pending = 0;
+  }
+  return SFM_HIP_OK;
+}
+
 inline int sync_all(sfm_hip_ctx* ctx) {
+  if (int rc = finish_uploads(ctx)) return rc;
   if (ctx->distance_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->distance_stream));
   for (hipStream_t t : ctx->tail_streams)
     if (t) HIP_TRY(ctx, hipStreamSynchronize(t));

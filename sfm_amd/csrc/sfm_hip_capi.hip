@@ -274,7 +274,8 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
 const char* sfm_hip_last_error(const sfm_hip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
 
 namespace {
-int upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n, hipMemcpyKind kind) {
+int upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n, hipMemcpyKind kind,
+                 bool blocking = true) {
   if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
   if (n < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative descriptor count");
   if (n > 0 && !descriptors) return fail(ctx, SFM_HIP_ERR_INVALID, "descriptors is null");
@@ -316,11 +317,13 @@ int upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, i
                        im.split, im.scale, im.n_pad);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(up);
+  if (e == hipSuccess && blocking) e = hipStreamSynchronize(up);
   if (e != hipSuccess) {
+    (void)hipStreamSynchronize(up);   // nothing queued above may still write into the block that is freed now
     free_image(im);
     return fail(ctx, SFM_HIP_ERR_HIP, std::string("image upload: ") + hipGetErrorString(e));
   }
+  if (!blocking) ctx->uploads_pending++;
   ctx->images[image_id] = im;
   return SFM_HIP_OK;
 }
@@ -328,6 +331,10 @@ int upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, i
 
 int sfm_hip_upload_image(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n) {
   return upload_image(ctx, image_id, descriptors, n, hipMemcpyHostToDevice);
+}
+
+int sfm_hip_upload_image_async(sfm_hip_ctx* ctx, int64_t image_id, const float* descriptors, int32_t n) {
+  return upload_image(ctx, image_id, descriptors, n, hipMemcpyHostToDevice, false);
 }
 
 int sfm_hip_upload_image_device(sfm_hip_ctx* ctx, int64_t image_id, const float* device_descriptors, int32_t n) {
@@ -373,6 +380,7 @@ int sfm_hip_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pai
     return fail(ctx, SFM_HIP_ERR_INVALID, "null pair list or output buffer");
   if (out_stride < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative out_stride");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rc = finish_uploads(ctx)) return rc;
 
   // validate everything before queuing anything
   std::vector<PairPlan> plans((size_t)n_pairs);
@@ -694,6 +702,7 @@ int sfm_hip_match_pair_noalloc(sfm_hip_ctx* ctx, int64_t first_image, int64_t se
   if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
   if (!out_count || !out_lhs_idx || !out_rhs_idx) return fail(ctx, SFM_HIP_ERR_INVALID, "null output buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rc = finish_uploads(ctx)) return rc;   // (a stream wait, no allocation)
   auto ix = ctx->images.find(first_image);
   auto iy = ctx->images.find(second_image);
   if (ix == ctx->images.end() || iy == ctx->images.end())

@@ -259,6 +259,7 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
     return fail(ctx, SFM_HIP_ERR_INVALID, "null pair list or output buffer");
   if (out_stride < 0) return fail(ctx, SFM_HIP_ERR_INVALID, "negative out_stride");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rc = finish_uploads(ctx)) return rc;
 
   // validate everything before queuing anything
   std::vector<std::pair<const Image*, const Image*>> plan((size_t)n_pairs);

@@ -119,8 +119,10 @@ void run_device(int device, const std::vector<PairJob>& jobs, const std::vector<
       const Descriptors* ds[2] = {jobs[p].first, jobs[p].second};
       for (int k = 0; k < 2; k++) {
         if (!uploaded.insert(ids[k]).second) continue;
-        if (sfm_hip_upload_image(ctx, ids[k], ds[k]->data(), (int32_t)ds[k]->size()) != SFM_HIP_OK)
-          fail(ctx, "sfm_hip_upload_image");
+        // queued, not waited for (the descriptors live in sfm_data for the whole call): the uploads of a
+        // batch's new images overlap each other, and the library waits for them when the batch is queued
+        if (sfm_hip_upload_image_async(ctx, ids[k], ds[k]->data(), (int32_t)ds[k]->size()) != SFM_HIP_OK)
+          fail(ctx, "sfm_hip_upload_image_async");
       }
     }
   };

@@ -65,7 +65,7 @@ void run_device(int device, const SfMData& scene, const std::vector<int64_t>& fl
   for (size_t k = 0; k < flat_pairs.size(); k++) ids.insert(flat_pairs[k]);
   for (IndexT id : ids) {
     const Descriptors& d = scene.descriptors.at(id);
-    if (sfm_hip_upload_image(ctx, id, d.data(), (int32_t)d.size()) != SFM_HIP_OK) fail(ctx, "sfm_hip_upload_image");
+    if (sfm_hip_upload_image_async(ctx, id, d.data(), (int32_t)d.size()) != SFM_HIP_OK) fail(ctx, "sfm_hip_upload_image_async");
   }
   if (sfm_hip_cascade_prepare(ctx, flat_pairs.data(), (int32_t)(flat_pairs.size() / 2), nullptr) != SFM_HIP_OK)
     fail(ctx, "sfm_hip_cascade_prepare");

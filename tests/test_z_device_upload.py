@@ -69,3 +69,46 @@ def test_replicate_images_entry_point_one_context(matcher):
     import sfm_amd
     with pytest.raises(sfm_amd.SfmHipError, match="one GPU per context"):
         replicate_images([matcher, matcher], images)
+
+
+def test_uploads_that_are_not_waited_for():
+    """sfm_hip_upload_image_async: the copy and the preparation of an image are queued, the first call
+    that lets the GPU read images waits for them.  Same matches as after blocking uploads, for the
+    brute-force and the cascade-hash path, and an image can be replaced that way too."""
+    import sfm_amd
+    A, B, _ = synth.make_pair(1500, 1700, 600, seed=91)
+    C, D, _ = synth.make_pair(900, 1100, 300, seed=92)
+    m = sfm_amd.Matcher(0)
+    try:
+        m.upload(0, A)
+        m.upload(1, B)
+        m.upload(2, C)
+        m.upload(3, D)
+        want = m.match_pairs([(0, 1), (2, 3), (0, 3)], 0.8, True)
+        m.drop_all()
+        for i, d in enumerate((A, B, C, D)):
+            m.upload_async(i, d)
+        got = m.match_pairs([(0, 1), (2, 3), (0, 3)], 0.8, True)
+        for (l, r, d), (wl, wr, wd) in zip(got, want):
+            assert l.tolist() == wl.tolist() and r.tolist() == wr.tolist()
+            assert d.view(np.uint32).tolist() == wd.view(np.uint32).tolist()
+        # replace image 1 by D without waiting, match right away
+        m.upload_async(1, D)
+        (l, r, d), = m.match_pairs([(0, 1)], 0.8, True)
+        (wl, wr, wd) = want[2]
+        assert l.tolist() == wl.tolist() and r.tolist() == wr.tolist()
+        # the cascade-hash path reads images through the same stream
+        P, Q = synth.make_repetitive_set(2, 800, 0.5, 2, seed=8, sigma=0.002)
+        m.upload(10, P)
+        m.upload(11, Q)
+        m.cascade_prepare([(10, 11)])
+        cw = m.cascade_match_pairs([(10, 11)], True)
+        m.drop(10)
+        m.drop(11)
+        m.upload_async(10, P)
+        m.upload_async(11, Q)
+        m.cascade_prepare([(10, 11)])
+        cg = m.cascade_match_pairs([(10, 11)], True)
+        assert (cg[0][0], cg[0][1].tolist(), cg[0][2].tolist()) == (cw[0][0], cw[0][1].tolist(), cw[0][2].tolist())
+    finally:
+        m.close()
