@@ -100,7 +100,10 @@ int sfm_hip_upload_image_device(sfm_hip_ctx* ctx, int64_t image_id, const float*
  * Afterwards the contexts are as after n_ctx * n_images calls of sfm_hip_upload_image.
  * No counterpart in the reference, whose images only live in host memory
  * (brute_force_matcher.cc:47-52 copies them per task).  RCCL is loaded when this is first called;
- * without a loadable librccl the call fails with SFM_HIP_ERR_HIP and the contexts are unchanged.
+ * without a loadable librccl the call fails with SFM_HIP_ERR_HIP and the contexts are unchanged, as
+ * they are after any failure before the images are registered.  A failure while they are being
+ * registered (a GPU out of memory) removes the call's images from every context, so that the
+ * contexts still agree on what they hold; images the call did not name are never touched.
  * Contexts must sit on distinct devices.  Blocking; at most one call at a time per process. */
 typedef struct {
   double comm_init_s;   /* creating the communicators (first call for a set of devices only) */

@@ -439,13 +439,18 @@ template <int MODE>
 __device__ __forceinline__ void finish_candidate(const CascadePair& P, int g, int both_directions, WalkShared& sh,
                                                  uint32_t entry, size_t a_at, size_t b_at) {
   const int owner = (int)(entry >> 16), r = (int)(entry & 0xFFFFu);
-  // Bucket ids + index and the high halves of both records, all four loads on their way at once: one
-  // trip to memory instead of two (the candidates that pass the first test are few, so the high
-  // halves fetched for the ones the bucket ids then drop cost next to nothing).
+#ifdef SFM_WALK_LOADS_AT_ONCE   // timing experiments: all four loads of a candidate in one trip to memory
   const uint4 ma4 = global_load(reinterpret_cast<const uint4*>(P.a_meta) + (a_at + owner));
   const uint4 mb4 = global_load(reinterpret_cast<const uint4*>(P.b_meta) + (b_at + r));
   uint2 ah = global_load(P.a_hi + (a_at + owner)), bh = global_load(P.b_hi + (b_at + r));
   asm volatile("" : "+v"(ah.x), "+v"(ah.y), "+v"(bh.x), "+v"(bh.y));   // keeps the last two loads in front of the test below
+#else
+  // the bucket ids first: a pair of near-duplicates shares most of its six buckets and is dropped
+  // here in all groups but the lowest, before the high halves of its codes are fetched (fetching all
+  // four at once saves a trip to memory and 3 % of the kernel's time, for a third more traffic: 0.46 against 0.34 GB per batch)
+  const uint4 ma4 = global_load(reinterpret_cast<const uint4*>(P.a_meta) + (a_at + owner));
+  const uint4 mb4 = global_load(reinterpret_cast<const uint4*>(P.b_meta) + (b_at + r));
+#endif
   // a pair of near-duplicates shares most of its six buckets and is counted in the lowest such group only
   const uint32_t x0 = ma4.x ^ mb4.x, x1 = ma4.y ^ mb4.y, x2 = ma4.z ^ mb4.z;
   bool earlier = false;   // shares a bucket in a group before g: counted there
@@ -455,6 +460,9 @@ __device__ __forceinline__ void finish_candidate(const CascadePair& P, int g, in
   if (g > 3) earlier |= (x1 >> 16) == 0;
   if (g > 4) earlier |= (x2 & 0xFFFFu) == 0;
   if (earlier) return;
+#ifndef SFM_WALK_LOADS_AT_ONCE
+  const uint2 ah = global_load(P.a_hi + (a_at + owner)), bh = global_load(P.b_hi + (b_at + r));
+#endif
   const uint2 al = sh.own[owner], bl = sh.lo[r];
   const uint32_t h = __popc(al.x ^ bl.x) + __popc(al.y ^ bl.y) + __popc(ah.x ^ bh.x) + __popc(ah.y ^ bh.y);
   if (h > (uint32_t)MAX_HAMMING) return;

@@ -226,6 +226,13 @@ extern "C" int sfm_hip_replicate_images(sfm_hip_ctx* const* ctxs, int32_t n_ctx,
   if (rc != SFM_HIP_OK) {
     for (int r = 1; r < n_ctx; r++)
       if (!ctxs[r]->last_error.empty() && c0->last_error.empty()) c0->last_error = ctxs[r]->last_error;
+    // A GPU that ran out of memory part-way leaves every context with a different part of the set:
+    // none of the call's images stays anywhere, so that all contexts agree again.
+    const std::string why = c0->last_error;
+    for (int r = 0; r < n_ctx; r++)
+      for (int k = 0; k < n_images; k++)
+        if (ctxs[r]->images.count(image_ids[k])) (void)sfm_hip_drop_image(ctxs[r], image_ids[k]);
+    c0->last_error = why;
     return rc;
   }
   if (out_times) out_times->register_s = seconds_since(t0);
