@@ -724,6 +724,11 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:   # the one-rank rehearsal, started by hand
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
