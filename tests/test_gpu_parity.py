@@ -614,3 +614,34 @@ def test_calls_without_distances_return_the_same_matches(matcher):
         matcher.sync()
         for i in range(12):
             matcher.drop(900 + i)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_crowds_of_near_equal_distances_around_the_ratio_threshold(matcher, seed):
+    """Every query has a nearest column at distance r, a second at r / 0.8 * (1 + delta) with delta within
+    a few 1e-4 .. 1e-3 of the threshold either way, and six more columns a few 1e-4 apart right behind
+    it: closer together than a candidate key resolves (a key keeps eight bits of the distance's
+    mantissa), so the lists cannot rank them and the decision cannot come from keys.  The answers must
+    still be the oracle's, bit for bit -- through the exact distances of the candidates or the exact
+    full scan."""
+    rng = np.random.default_rng(seed)
+    na, per = 300, 8
+    A = synth.rootsift_rows(na, 700 + seed)
+    B = np.empty((na * per, 128), np.float32)
+    deltas = np.array([-2e-3, -5e-4, -2e-4, 2e-4, 5e-4, 2e-3])
+    for i in range(na):
+        r1 = 0.04 + 0.02 * rng.random()
+        r2 = r1 / 0.8 * (1.0 + deltas[i % len(deltas)])
+        radii = [r1, r2] + [r2 * (1.0 + 3e-4 * (k + 1)) for k in range(per - 2)]
+        for k, r in enumerate(radii):
+            e = rng.standard_normal(128)
+            e *= r / np.linalg.norm(e)
+            B[i * per + k] = (A[i].astype(np.float64) + e).astype(np.float32)
+    B = B[rng.permutation(len(B))]
+    for cross in (True, False):
+        got = run_pair(matcher, A, B, 0.8, cross)
+        exp = oracle.match_pair(A, B, 0.8, cross, threads=8)
+        assert_same(got, exp, "seed %d cross=%s" % (seed, cross))
+    # and the other way round (many queries, few columns each a near-tie for several of them)
+    got = run_pair(matcher, B, A, 0.8, True, ids=(2, 3))
+    assert_same(got, oracle.match_pair(B, A, 0.8, True, threads=8), "swapped")
