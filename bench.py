@@ -167,14 +167,15 @@ def cascade_leg(m, with_cpu, n_images=32, reps=40):
     # set's 128 MiB; MI355X_MICROARCH.md "Indexed rows", 151 MB table: 7.4-7.9 TB/s).  Compaction: its
     # stores go straight into the caller's pinned host memory, over PCIe (Gen5 x16, 63 GB/s).
     walk_ms, near_ms, comp_ms = sk["walk_ms"] / nb, sk["nearest_ms"] / nb, sk["compact_ms"] / nb
-    cand, close = sk["walk_candidates"] / nb, sk["close_pairs"] / nb
+    cand, close, exact = sk["walk_candidates"] / nb, sk["close_pairs"] / nb, sk["exact_distances"] / nb
     out_bytes = n_matches * 12.0 + len(pairs) * 8.0
     per_kernel = [
         kernel_roof("k_ch_walk_count", "vector instruction issue", cand * WALK_OPS_PER_CANDIDATE / (walk_ms * 1e-3) / 1e12,
                     PEAK_VALU_TOPS, "Tops/s (32-bit lane-operations)", walk_ms, candidates_per_batch=cand,
                     ops_per_candidate=WALK_OPS_PER_CANDIDATE),
-        kernel_roof("k_ch_nearest", "random gather of 512-byte rows", close * 1024.0 / (near_ms * 1e-3) / 1e9,
-                    PEAK_GATHER_GBPS, "GB/s", near_ms, close_pairs_per_batch=close, bytes_per_close_pair=1024),
+        kernel_roof("k_ch_nearest", "random gather of 512-byte rows", exact * 1024.0 / (near_ms * 1e-3) / 1e9,
+                    PEAK_GATHER_GBPS, "GB/s", near_ms, close_pairs_per_batch=close, exact_distances_per_batch=exact,
+                    bytes_per_exact_distance=1024),
         kernel_roof("k_ch_compact", "pcie", out_bytes / (comp_ms * 1e-3) / 1e9, PEAK_PCIE_GBPS, "GB/s", comp_ms,
                     bytes_to_host_per_batch=out_bytes),
     ]

@@ -278,8 +278,9 @@ typedef struct {
   double compact_ms;        /* k_ch_compact */
   uint64_t walk_candidates; /* (first-image descriptor, second-image descriptor, group) triples that share a
                                bucket: what the walk tests, each by the Hamming distance of two 64-bit halves */
-  uint64_t close_pairs;     /* entries of the close-pair lists (Hamming distance <= 10): each costs the exact
-                               distance of two 512-byte descriptor rows unless neither side takes its bin */
+  uint64_t close_pairs;     /* entries of the close-pair lists (Hamming distance <= 10) */
+  uint64_t exact_distances; /* ... of which either side takes the bin they fall in (.cc:95-105), so that the
+                               exact distance of their two 512-byte descriptor rows is computed */
 } sfm_hip_cascade_stats;
 
 /* The projection matrices of cascade_hash_matcher.cc:130-146: primary[128][128] (row i produces hash

@@ -47,7 +47,8 @@ class CascadeStats(ctypes.Structure):
                 ("match_ms", ctypes.c_double), ("match_bytes", ctypes.c_double),
                 ("list_overflows", ctypes.c_uint64), ("workspace_dirty_words", ctypes.c_uint64),
                 ("walk_ms", ctypes.c_double), ("nearest_ms", ctypes.c_double), ("fallback_ms", ctypes.c_double),
-                ("compact_ms", ctypes.c_double), ("walk_candidates", ctypes.c_uint64), ("close_pairs", ctypes.c_uint64)]
+                ("compact_ms", ctypes.c_double), ("walk_candidates", ctypes.c_uint64), ("close_pairs", ctypes.c_uint64),
+                ("exact_distances", ctypes.c_uint64)]
 
 
 class GeometryStats(ctypes.Structure):

@@ -627,7 +627,8 @@ constexpr int NEAREST_MAX_SEGMENTS = GROUPS * (MAX_IMAGE_ROWS / 256);
 constexpr int NEAREST_TILE = 64;
 constexpr int NEAREST_SQ_STRIDE = 132;   // words per row of squares (128 + 4: conflict-free 16-byte reads)
 
-// work (may be null): counter that receives the number of list entries, for the statistics.
+// work (may be null): for the statistics; work[0] receives the number of list entries, one of the
+// WORK_SLOTS counters from work[2 + WORK_SLOTS] on the number of exact distances computed.
 __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __restrict__ pairs, int both_directions,
                                                        int segments, unsigned long long* __restrict__ work) {
   extern __shared__ uint32_t start[];   // start[s] = entries in the segments before s
@@ -665,6 +666,7 @@ __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __rest
   __syncthreads();
   const uint32_t total = start[segments];
   if (work && blockIdx.x == 0 && tid == 0 && total) atomicAdd(work, (unsigned long long)total);
+  unsigned long long needed = 0;   // entries whose distance this workgroup computes (the same in every lane of wave 0)
   for (uint32_t t0 = blockIdx.x * NEAREST_TILE; t0 < total; t0 += gridDim.x * NEAREST_TILE) {
     // one lane per entry: the bins decisions
     if (tid < NEAREST_TILE) {
@@ -695,6 +697,7 @@ __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __rest
       ent_i[tid] = i;
       ent_j[tid] = j;
       ent_f[tid] = f;
+      if (work) needed += (unsigned long long)__popcll(__ballot(f != 0));   // statistics only
     }
     __syncthreads();
     // 32 lanes per row: eight entries per half-wavefront, all sixteen loads on their way before the
@@ -739,6 +742,10 @@ __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __rest
     }
     __syncthreads();   // the tile's arrays are free again
   }
+  // one of WORK_SLOTS counters (a single one would serialise the launch's atomics); they lie behind the
+  // walk's WORK_SLOTS counters, which start two words after work[0]
+  if (work && tid == 0 && needed)
+    atomicAdd(work + 2 + WORK_SLOTS + ((blockIdx.z * gridDim.x + blockIdx.x) & (WORK_SLOTS - 1)), needed);
 }
 
 // The bins decision for every query of a pair whose list overflowed.  One thread per query;

@@ -52,8 +52,9 @@ int find_images(sfm_hip_ctx* ctx, const int64_t* ids, int32_t n, std::vector<Ima
 // Events of a timed batch: in front of the walk, behind it, behind the nearest kernel, behind the
 // two fallback kernels, behind the compaction.
 constexpr size_t BATCH_MARKS = 5;
-// cascade_counters: list overflows, scratch for checks, close pairs, -, then the walk's candidate counters
-constexpr int N_COUNTERS = 4 + (int)WORK_SLOTS;
+// cascade_counters: list overflows, scratch for checks, close pairs, -, then WORK_SLOTS counters of the walk's
+// candidates and WORK_SLOTS of the exact distances
+constexpr int N_COUNTERS = 4 + 2 * (int)WORK_SLOTS;
 
 int fold_cascade_timing(sfm_hip_ctx* ctx) {
   for (size_t k = 0; k + BATCH_MARKS <= ctx->cascade_timing.size(); k += BATCH_MARKS) {
@@ -542,8 +543,11 @@ int sfm_hip_cascade_get_stats(sfm_hip_ctx* ctx, sfm_hip_cascade_stats* out) {
     ctx->cascade_stats.list_overflows = c[0];
     ctx->cascade_stats.workspace_dirty_words = c[1];
     ctx->cascade_stats.close_pairs = c[2];
-    ctx->cascade_stats.walk_candidates = 0;
-    for (int k = 4; k < N_COUNTERS; k++) ctx->cascade_stats.walk_candidates += c[k];
+    ctx->cascade_stats.walk_candidates = ctx->cascade_stats.exact_distances = 0;
+    for (int k = 0; k < (int)WORK_SLOTS; k++) {
+      ctx->cascade_stats.walk_candidates += c[4 + k];
+      ctx->cascade_stats.exact_distances += c[4 + WORK_SLOTS + k];
+    }
   }
   *out = ctx->cascade_stats;
   return SFM_HIP_OK;

@@ -385,7 +385,7 @@ def test_per_kernel_statistics_leave_the_matches_alone(matcher):
         assert (got[0][0], got[0][1].tolist(), got[0][2].tolist()) == (plain[0][0], plain[0][1].tolist(), plain[0][2].tolist())
     assert st["match_launches"] == 1 and st["walk_ms"] > 0 and st["nearest_ms"] > 0 and st["compact_ms"] > 0
     assert st["walk_ms"] + st["nearest_ms"] + st["fallback_ms"] + st["compact_ms"] <= st["match_ms"] * 1.001
-    assert st["walk_candidates"] >= st["close_pairs"] >= len(plain[0][1]) > 50
+    assert st["walk_candidates"] >= st["close_pairs"] >= st["exact_distances"] >= len(plain[0][1]) > 50
     # bucket sharing is symmetric: the count equals the sum over groups and buckets of |A_b| * |B_b|
     _, bids_a = matcher.cascade_get_hashes(0)
     _, bids_b = matcher.cascade_get_hashes(1)
