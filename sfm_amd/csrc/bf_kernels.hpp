@@ -1600,7 +1600,10 @@ __global__ __launch_bounds__(256, 4) void k_rerank(const PairDev* __restrict__ p
       }
     }
     const uint32_t bound = bnd[tid];
-    bool safe = provable && (no <= NCAND || bound == SENT);
+    // (Few columns on the other side do not make the candidates complete by themselves: the four rows
+    // of a four-row image sit in ONE lane's two-entry column list, which drops two of them -- by index
+    // when their keys tie.  Only lists that dropped nothing, bound == SENT, need no proof.)
+    bool safe = provable && bound == SENT;
     if (provable && !safe) {
       const uint32_t mask = KEY_MASK;
       if (engine == ENGINE_F32) {
