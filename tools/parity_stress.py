@@ -1,9 +1,14 @@
 """Randomised parity run of the HIP path against the CPU oracle, beyond what the test suite holds:
-    python tools/parity_stress.py [--seconds 90] [--seed 1]
-Random image sizes and four kinds of descriptors (RootSIFT-like rows with planted near-copies, Gaussian
+    python tools/parity_stress.py [--path brute|cascade|geometry] [--seconds 90] [--seed 1]
+brute (the default): random image sizes and four kinds of descriptors (RootSIFT-like rows with planted near-copies, Gaussian
 rows, rows on a small integer lattice -- full of exact ties --, crowds of near-duplicates), both distance
 engines, with and without cross-check, ratios near and far from 0.8.  Indices and distance bits must be
-the oracle's.  Prints one line per hundred pairs and a summary; exits non-zero on the first difference."""
+the oracle's.  cascade: sets of two to four images (repeated structure with noise of random size, plain
+RootSIFT-like rows, crowds of near-duplicates, lattice rows; sizes 0 ... 3000), every pair of a set, with and
+without cross-check: default records, indices and distance bits.  geometry: calls of one to six pairs of 0 ...
+3000 matches with random inlier fractions and noise: verdict, matrix bits, flags, rounds.
+Prints a line every so many pairs and a summary; exits non-zero on the first difference (the inputs go to
+gpurun_out/parity_difference.npz)."""
 import argparse
 import os
 import sys
@@ -31,11 +36,109 @@ def make(kind, na, nb, rng):
     return pick(na), pick(nb)
 
 
+def dump(**arrays):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    np.savez(os.path.join(out, "parity_difference.npz"), **arrays)
+
+
+def cascade_image(kind, n, rng, shared):
+    if kind == 0:
+        return shared[int(rng.integers(len(shared)))][:n]
+    if kind == 1:
+        return synth.rootsift_rows(n, int(rng.integers(1 << 30)))
+    if kind == 2:
+        return rng.integers(0, 3, (n, 128)).astype(np.float32)
+    base = synth.rootsift_rows(max(4, n // 6), int(rng.integers(1 << 30)))
+    return (base[rng.integers(0, len(base), n)] + rng.standard_normal((n, 128)) * 10.0 ** rng.uniform(-6, -2)).astype(np.float32)
+
+
+def run_cascade(a):
+    from oracle import cascade
+    rng = np.random.default_rng(a.seed)
+    m = sfm_amd.Matcher(0)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < a.seconds:
+        k = int(rng.integers(2, 5))
+        kind = int(rng.integers(0, 4))
+        shared = synth.make_repetitive_set(k, 3000, float(rng.uniform(0.2, 0.9)), int(rng.integers(1, 5)),
+                                           seed=int(rng.integers(1 << 30)), sigma=float(10.0 ** rng.uniform(-4, -2)))
+        images = {}
+        for i in range(k):
+            size = int(2 ** rng.uniform(0, 11.55)) if rng.integers(0, 12) else int(rng.integers(0, 3))
+            images[3 * i + 1] = np.ascontiguousarray(cascade_image(kind, size, rng, shared))
+        ids = sorted(images)
+        pairs = [(x, y) for u, x in enumerate(ids) for y in ids[u + 1:]]
+        m.drop_all()
+        for i, d in images.items():
+            m.upload(i, d)
+        m.cascade_prepare(pairs)
+        order = cascade.image_order(pairs)
+        mean = cascade.mean([images[int(i)] for i in order])
+        for cross in (False, True):
+            got = m.cascade_match_pairs(pairs, cross_check=cross)
+            for (x, y), (nd, l, r, d) in zip(pairs, got):
+                wnd, wl, wr, wd = cascade.match_pair(images[x], images[y], mean, cross)
+                if nd != wnd or l.tolist() != wl.tolist() or r.tolist() != wr.tolist() or \
+                        d.view(np.uint32).tolist() != wd.view(np.uint32).tolist():
+                    print("DIFFERENCE: cascade, kind %d, images %s, pair (%d, %d), cross %s, seed %d, set %d"
+                          % (kind, [len(images[i]) for i in ids], x, y, cross, a.seed, n))
+                    dump(mean=mean, cross=cross, pair=np.array([x, y]), **{"image%d" % i: images[i] for i in ids})
+                    sys.exit(1)
+        n += 1
+        if n % 20 == 0:
+            print("%d sets identical (%.0f s)" % (n, time.perf_counter() - t0), flush=True)
+    st = m.cascade_stats()
+    m.close()
+    print("done: %d sets of images, every pair with and without cross-check, identical to the oracle; "
+          "list overflows %d" % (n, st["list_overflows"]))
+
+
+def run_geometry(a):
+    from oracle import geometry
+    rng = np.random.default_rng(a.seed)
+    m = sfm_amd.Matcher(0)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < a.seconds:
+        sets = []
+        for _ in range(int(rng.integers(1, 7))):
+            size = int(2 ** rng.uniform(0, 11.55)) if rng.integers(0, 10) else int(rng.integers(0, 9))
+            noise = float(rng.choice([0.0, 0.1, 0.5, 2.0]))
+            l, r, _ = synth.make_two_view_matches(size, float(rng.uniform(0.1, 1.0)), seed=int(rng.integers(1 << 30)), noise=noise)
+            if rng.integers(0, 8) == 0 and size > 1:      # repeated matches: degenerate samples
+                pick = rng.integers(0, max(1, size // 8), size)
+                l, r = np.ascontiguousarray(l[pick]), np.ascontiguousarray(r[pick])
+            sets.append((l, r))
+        seed = int(rng.integers(1 << 30))
+        first = int(rng.integers(0, 1000))
+        got = m.geometry_verify_pairs(sets, seed=seed, first_pair_index=first)
+        for k, ((l, r), (ok, F, flags, rounds)) in enumerate(zip(sets, got)):
+            wok, wF, wflags, wrounds = geometry.compute_fundamental(l, r, seed=seed, pair=first + k)
+            if ok != wok or rounds != wrounds or F.view(np.uint64).tolist() != wF.view(np.uint64).tolist() or \
+                    flags.tolist() != wflags.tolist():
+                print("DIFFERENCE: geometry, %d matches, seed %d, pair index %d, run seed %d, call %d: rounds %d / %d, verdict %s / %s"
+                      % (len(l), seed, first + k, a.seed, n, rounds, wrounds, ok, wok))
+                dump(l=l, r=r, seed=seed, pair=first + k)
+                sys.exit(1)
+            n += 1
+        if n % 50 < len(sets):
+            print("%d pairs identical (%.0f s)" % (n, time.perf_counter() - t0), flush=True)
+    m.close()
+    print("done: %d pairs, identical to the oracle" % n)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--path", choices=("brute", "cascade", "geometry"), default="brute")
     ap.add_argument("--seconds", type=float, default=90.0)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
+    if a.path == "cascade":
+        return run_cascade(a)
+    if a.path == "geometry":
+        return run_geometry(a)
     rng = np.random.default_rng(a.seed)
     m = sfm_amd.Matcher(0)
     t0 = time.perf_counter()
@@ -61,9 +164,7 @@ def main():
                       % (kind, na, nb, ratio, cross, engine, a.seed, n))
                 print("got ", l.tolist(), r.tolist(), d.view(np.uint32).tolist())
                 print("want", want[0].tolist(), want[1].tolist(), want[2].view(np.uint32).tolist())
-                out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-                os.makedirs(out, exist_ok=True)
-                np.savez(os.path.join(out, "parity_difference.npz"), A=A, B=B, ratio=ratio, cross=cross)
+                dump(A=A, B=B, ratio=ratio, cross=cross)
                 sys.exit(1)
         n += 1
         if n % 100 == 0:
