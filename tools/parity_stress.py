@@ -1,9 +1,11 @@
 """Randomised parity run of the HIP path against the CPU oracle, beyond what the test suite holds:
-    python tools/parity_stress.py [--path brute|cascade|geometry] [--seconds 90] [--seed 1]
+    python tools/parity_stress.py [--path brute|batch|cascade|geometry] [--seconds 90] [--seed 1]
 brute (the default): random image sizes and four kinds of descriptors (RootSIFT-like rows with planted near-copies, Gaussian
 rows, rows on a small integer lattice -- full of exact ties --, crowds of near-duplicates), both distance
 engines, with and without cross-check, ratios near and far from 0.8.  Indices and distance bits must be
-the oracle's.  cascade: sets of two to four images (repeated structure with noise of random size, plain
+the oracle's.  batch: sets of three to seven images of random sizes that share rows, every ordered pair in one
+call of sfm_hip_match_pairs (the batched kernels), and one pair of the set through
+sfm_hip_match_pair_noalloc.  cascade: sets of two to four images (repeated structure with noise of random size, plain
 RootSIFT-like rows, crowds of near-duplicates, lattice rows; sizes 0 ... 3000), every pair of a set, with and
 without cross-check: default records, indices and distance bits.  geometry: calls of one to six pairs of 0 ...
 3000 matches with random inlier fractions and noise: verdict, matrix bits, flags, rounds.
@@ -95,6 +97,68 @@ def run_cascade(a):
           "list overflows %d" % (n, st["list_overflows"]))
 
 
+def run_batch(a):
+    rng = np.random.default_rng(a.seed)
+    m = sfm_amd.Matcher(0)
+    cap = 8192
+    bufs = [m.pinned((1,), np.int32), m.pinned((cap,), np.int32), m.pinned((cap,), np.int32), m.pinned((cap,), np.float32)]
+    t0 = time.perf_counter()
+    n = 0
+    n_pairs = 0
+    while time.perf_counter() - t0 < a.seconds:
+        k = int(rng.integers(3, 8))
+        kind = int(rng.integers(0, 4))
+        pool = synth.rootsift_rows(2500, int(rng.integers(1 << 30)))
+        images = {}
+        for i in range(k):
+            size = int(2 ** rng.uniform(0, 11.2)) if rng.integers(0, 12) else int(rng.integers(0, 3))
+            if kind == 0:      # noisy copies of rows of a common pool, and rows of its own
+                own = synth.rootsift_rows(size, int(rng.integers(1 << 30)))
+                take = rng.random(size) < 0.5
+                d = np.where(take[:, None], pool[rng.integers(0, len(pool), size)] + rng.standard_normal((size, 128)) * 0.01, own)
+            elif kind == 1:
+                d = rng.standard_normal((size, 128))
+            elif kind == 2:
+                d = rng.integers(0, 3, (size, 128))
+            else:              # crowds of near-duplicates of a few pool rows
+                d = pool[rng.integers(0, max(4, size // 6), size)] + rng.standard_normal((size, 128)) * 10.0 ** rng.uniform(-6, -2)
+            images[5 * i + 2] = np.ascontiguousarray(d, dtype=np.float32)
+        ids = sorted(images)
+        pairs = [(x, y) for x in ids for y in ids if x != y]
+        ratio = float(rng.choice([0.8, 0.8, 0.6, 0.95, 1.0]))
+        cross = bool(rng.integers(0, 2))
+        want = [oracle.match_pair(images[x], images[y], ratio, cross, threads=8) for x, y in pairs]
+        m.drop_all()
+        for i, d in images.items():
+            m.upload_async(i, d)
+        for engine in ("f32", "f16x3"):
+            m.set_engine(engine)
+            got = m.match_pairs(pairs, ratio, cross)
+            pick = int(rng.integers(len(pairs)))
+            m.match_pair_noalloc_async(pairs[pick][0], pairs[pick][1], ratio, cross, *bufs)
+            m.sync()
+            c = int(bufs[0].array[0])
+            got.append((bufs[1].array[:c].astype(np.int64), bufs[2].array[:c].astype(np.int64), bufs[3].array[:c].copy()))
+            for which, ((x, y), (l, r, d), w) in enumerate(zip(pairs + [pairs[pick]], got, want + [want[pick]])):
+                if l.tolist() != w[0].tolist() or r.tolist() != w[1].tolist() or \
+                        d.view(np.uint32).tolist() != w[2].view(np.uint32).tolist():
+                    print("DIFFERENCE: batch, kind %d, images %s, pair (%d, %d)%s, ratio %g, cross %s, engine %s, seed %d, set %d"
+                          % (kind, [len(images[i]) for i in ids], x, y, " through the allocation-free entry point" if which == len(pairs) else "",
+                             ratio, cross, engine, a.seed, n))
+                    dump(A=images[x], B=images[y], ratio=ratio, cross=cross, **{"image%d" % i: images[i] for i in ids})
+                    sys.exit(1)
+        n += 1
+        n_pairs += len(pairs)
+        if n % 20 == 0:
+            print("%d sets, %d pairs identical on both engines (%.0f s)" % (n, n_pairs, time.perf_counter() - t0), flush=True)
+    m.sync()
+    for b in bufs:
+        b.free()
+    m.close()
+    print("done: %d sets, %d pairs in batches and %d through the allocation-free entry point, both engines, identical to the oracle"
+          % (n, n_pairs, n))
+
+
 def run_geometry(a):
     from oracle import geometry
     rng = np.random.default_rng(a.seed)
@@ -131,10 +195,12 @@ def run_geometry(a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--path", choices=("brute", "cascade", "geometry"), default="brute")
+    ap.add_argument("--path", choices=("brute", "batch", "cascade", "geometry"), default="brute")
     ap.add_argument("--seconds", type=float, default=90.0)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
+    if a.path == "batch":
+        return run_batch(a)
     if a.path == "cascade":
         return run_cascade(a)
     if a.path == "geometry":
