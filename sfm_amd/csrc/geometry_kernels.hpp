@@ -30,6 +30,7 @@ constexpr uint32_t MAX_ROUNDS = 4096;     // MaxEpoch, ransac.hpp:97
 constexpr int ROUNDS_PER_LAUNCH = 256;
 constexpr int HYP_THREADS = 64;           // one wavefront: the fit needs most of the register file
 constexpr int SWEEPS9 = 12, SWEEPS3 = 8;
+constexpr int THR_CHUNK = 128;            // positions per table of sampling thresholds (k_geo_fit)
 
 struct GeoState {
   double best_F[9];
@@ -237,27 +238,97 @@ __global__ __launch_bounds__(HYP_THREADS) void k_geo_fit(const GeoPair* __restri
   if (st->done) return;
   const uint32_t slot = blockIdx.x * HYP_THREADS + threadIdx.x;
   const uint32_t round = first_round + slot;
-  if (round >= st->rounds_limit) return;   // the limit only ever comes down: never looked at
+  // the limit only ever comes down: a round at or beyond it is never looked at.  Its lane still
+  // helps with the threshold table below.
+  const bool active = round < st->rounds_limit;
+  if (!__any(active)) return;
   const uint32_t n = (uint32_t)P.n;
   const uint64_t key = round_key(P.stream, round);
-  // ransac.hpp:34-59: a rotating offset, then selection sampling in index order
+  // ransac.hpp:34-59: a rotating offset, then selection sampling in index order: match i is taken
+  // when u_i < (8 - selected) / (n - i), u_i = (53 bits of the stream's word 1 + i) * 2^-53.
   int idx[SAMPLE];
-#pragma unroll
-  for (int k = 0; k < SAMPLE; k++) idx[k] = 0;
+#if defined(SFM_GEO_ABLATE) && SFM_GEO_ABLATE == 1
+  // diagnostic build: no sampling (eight consecutive matches)
+  for (int k = 0; k < SAMPLE; k++) idx[k] = (int)((round * 8u + k + (uint32_t)key) % n);
+#else
   {
+    // The walk looks at some 0.9 n matches per round and takes eight, so what it costs is what it
+    // does per match it does NOT take.  u < p, with p the double quotient above, says the same as
+    // (word >> 11) < ceil(p * 2^53) in integers (both scalings are exact), and p depends on the
+    // position and on how many are taken already, not on the round: the wavefront tabulates the
+    // thresholds of 128 positions x 8 counts at a time (sixteen divisions per lane where every lane
+    // had 128) and a match is then one hash of the counter, one LDS read and one 64-bit compare.
+    __shared__ uint64_t thr[SAMPLE][THR_CHUNK];
+    __shared__ int32_t picks[SAMPLE][HYP_THREADS];
+    const uint32_t lane = threadIdx.x;
     const uint32_t offset = (uint32_t)(stream_word(key, 0) % (uint64_t)(n + 1));
-    int selected = 0;
-    for (uint32_t i = 0; i < n && selected < SAMPLE; i++) {
-      const double select_probability = (double)(SAMPLE - selected) / (double)(n - i);
-      const double u = (double)(stream_word(key, 1 + i) >> 11) * 0x1.0p-53;
-      if (u < select_probability) {
-        const int pick = (int)((offset + i) % n);
-#pragma unroll
-        for (int k = 0; k < SAMPLE; k++) idx[k] = selected == k ? pick : idx[k];
-        selected++;
+    uint32_t pos = offset >= n ? offset - n : offset;           // (offset + i) % n, kept up by counting
+    uint64_t counter = key + 2 * 0x9E3779B97F4A7C15ull;           // stream_word(key, 1 + i) = mix64(key + (i + 2) * step)
+    int selected = active ? 0 : SAMPLE;
+    for (uint32_t i0 = 0; i0 < n; i0 += THR_CHUNK) {
+      for (uint32_t e = lane; e < SAMPLE * THR_CHUNK; e += HYP_THREADS) {
+        const uint32_t taken = e / THR_CHUNK, c = e % THR_CHUNK, i = i0 + c;
+        uint64_t t = 0;
+        if (i < n) {
+          const double select_probability = (double)(SAMPLE - (int)taken) / (double)(n - i);
+          t = (uint64_t)ceil(select_probability * 0x1.0p53);   // <= 2^56
+        }
+        thr[taken][c] = t;
       }
+      __syncthreads();
+      // Four positions per step, their thresholds for the count on entry and for one more read
+      // before the hashes are computed (a wavefront alone on its SIMD has nothing else to cover an
+      // LDS read with); a lane that takes two of the four reads again.  Positions past n have
+      // threshold 0 and are never taken.
+      const uint32_t lim = n - i0 < (uint32_t)THR_CHUNK ? n - i0 : (uint32_t)THR_CHUNK;
+      for (uint32_t c = 0; c < lim && __any(selected < SAMPLE); c += 4) {
+        const int s0 = selected & (SAMPLE - 1), s1 = (selected + 1) & (SAMPLE - 1);
+        uint64_t ta[4], tb[4], word[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          ta[e] = thr[s0][c + e];
+          tb[e] = thr[s1][c + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) word[e] = mix64(counter + (uint64_t)e * 0x9E3779B97F4A7C15ull) >> 11;
+        counter += 4 * 0x9E3779B97F4A7C15ull;
+        // the four hashes in one block of straight code, where their chains overlap (left alone the
+        // compiler moves each one behind the branch of the position before it)
+#pragma unroll
+        for (int e = 0; e < 4; e++) asm volatile("" : "+v"(word[e]));
+        const int on_entry = selected;
+        int resume = 4;     // a lane that has taken two of the four goes on from here, reading again
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint64_t t = selected == on_entry ? ta[e] : tb[e];
+          if (resume == 4 && selected < SAMPLE && word[e] < t) {
+            const uint32_t at = pos + e;
+            picks[selected][lane] = (int32_t)(at >= n ? at - n : at);
+            selected++;
+            if (selected == on_entry + 2) resume = e + 1;
+          }
+        }
+        if (__any(resume < 4 && selected < SAMPLE)) {
+#pragma unroll
+          for (int e = 2; e < 4; e++) {
+            if (e >= resume && selected < SAMPLE && word[e] < thr[selected & (SAMPLE - 1)][c + e]) {
+              const uint32_t at = pos + e;
+              picks[selected][lane] = (int32_t)(at >= n ? at - n : at);
+              selected++;
+            }
+          }
+        }
+        pos += 4;
+        pos = pos >= n ? pos - n : pos;
+      }
+      __syncthreads();
+      if (!__any(selected < SAMPLE)) break;
     }
+#pragma unroll
+    for (int k = 0; k < SAMPLE; k++) idx[k] = k < selected ? picks[k][lane] : 0;
   }
+#endif
+  if (!active) return;
   double px[SAMPLE], py[SAMPLE], qx[SAMPLE], qy[SAMPLE];
 #pragma unroll
   for (int k = 0; k < SAMPLE; k++) {
@@ -266,7 +337,12 @@ __global__ __launch_bounds__(HYP_THREADS) void k_geo_fit(const GeoPair* __restri
     px[k] = a.x; py[k] = a.y; qx[k] = b.x; qy[k] = b.y;
   }
   double F[9];
+#if defined(SFM_GEO_ABLATE) && SFM_GEO_ABLATE == 2
+  // diagnostic build: no fit
+  for (int k = 0; k < 9; k++) F[k] = px[k & 7] + qy[(k + 3) & 7];
+#else
   fit_eight(px, py, qx, qy, F);
+#endif
 #pragma unroll
   for (int k = 0; k < 9; k++) P.hyp_F[(size_t)slot * 9 + k] = F[k];
 #pragma unroll
