@@ -96,7 +96,8 @@ struct alignas(16) HashMeta {
 // its own because the compaction reads nothing else, a result of 4 words.
 constexpr int HIST_WORDS = 12;
 constexpr int RES_WORDS = 4;
-constexpr int RES_STATE = 0;       // 0: no close candidate seen; 1: seen, but no match; 2 + h: match, bins 0..h taken
+constexpr int RES_STATE = 0;       // 1: seen, but no match; 2 + h: match, bins 0..h taken; 0: not seen, or not stored (k_ch_nearest
+                                   // stores it only where no distance will mark the slot: touched = state or minimum non-zero)
 constexpr int RES_BEST = 2;        // [2, 3] 64-bit maximum of ~(distance bits << 32 | index): the minimum, inverted
 constexpr int SLOT_WORDS = HIST_WORDS + RES_WORDS;   // per query
 constexpr uint32_t STATE_NONE = 1;
@@ -603,14 +604,16 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ch_walk_count(const CascadePai
   walk_block<WALK_COUNT>(pairs[blockIdx.z], blockIdx.y, blockIdx.x, gridDim.x, both_directions, sh, work);
 }
 
-// NEAREST: grid (a few, 6, pairs); returns at once unless the pair's list overflowed, else the
-// workgroups stride the pair's records.
+// NEAREST: grid (a few, 1, pairs); returns at once unless the pair's list overflowed, else the
+// workgroups stride the pair's (group, 256 records) items.  (Few workgroups per pair on purpose:
+// nearly every launch finds nothing to do, and what it costs then is its number of workgroups.)
 __global__ __launch_bounds__(WALK_THREADS) void k_ch_walk_nearest(const CascadePair* __restrict__ pairs, int both_directions) {
   __shared__ WalkShared sh;
   const CascadePair& P = pairs[blockIdx.z];
   if (*P.overflow == 0) return;
   const int nbx = (P.na + WALK_THREADS - 1) / WALK_THREADS;
-  for (int bx = blockIdx.x; bx < nbx; bx += gridDim.x) walk_block<WALK_NEAREST>(P, blockIdx.y, bx, nbx, both_directions, sh);
+  for (int item = blockIdx.x; item < GROUPS * nbx; item += gridDim.x)
+    walk_block<WALK_NEAREST>(P, item / nbx, item % nbx, nbx, both_directions, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,7 +627,11 @@ __global__ __launch_bounds__(WALK_THREADS) void k_ch_walk_nearest(const CascadeP
 // Dynamic LDS: (segments + 1) words.
 // ---------------------------------------------------------------------------------------------
 constexpr int NEAREST_MAX_SEGMENTS = GROUPS * (MAX_IMAGE_ROWS / 256);
-constexpr int NEAREST_TILE = 64;
+constexpr int NEAREST_TILE = 64;       // close pairs whose squares are in LDS at a time
+#ifndef SFM_NEAREST_SUPER   // (overridden in timing experiments: tools/build_variant.sh)
+#define SFM_NEAREST_SUPER 256
+#endif
+constexpr int NEAREST_SUPER = SFM_NEAREST_SUPER;     // close pairs whose bins decisions are taken together: four tiles
 constexpr int NEAREST_SQ_STRIDE = 132;   // words per row of squares (128 + 4: conflict-free 16-byte reads)
 
 // work (may be null): for the statistics; work[0] receives the number of list entries, one of the
@@ -634,7 +641,7 @@ __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __rest
   extern __shared__ uint32_t start[];   // start[s] = entries in the segments before s
   __shared__ uint32_t wave_sum[4];
   __shared__ __attribute__((aligned(16))) float sq[NEAREST_TILE * NEAREST_SQ_STRIDE];
-  __shared__ uint32_t ent_i[NEAREST_TILE], ent_j[NEAREST_TILE], ent_f[NEAREST_TILE];   // ent_f: 1 = into a, 2 = into b
+  __shared__ uint32_t ent_i[NEAREST_SUPER], ent_j[NEAREST_SUPER], ent_f[NEAREST_SUPER];   // ent_f: 1 = into a, 2 = into b
   const CascadePair& P = pairs[blockIdx.z];
   if (*P.overflow != 0) return;   // incomplete list: k_ch_take_all + k_ch_walk_nearest do this pair
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -666,13 +673,19 @@ __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __rest
   __syncthreads();
   const uint32_t total = start[segments];
   if (work && blockIdx.x == 0 && tid == 0 && total) atomicAdd(work, (unsigned long long)total);
-  unsigned long long needed = 0;   // entries whose distance this workgroup computes (the same in every lane of wave 0)
-  for (uint32_t t0 = blockIdx.x * NEAREST_TILE; t0 < total; t0 += gridDim.x * NEAREST_TILE) {
-    // one lane per entry: the bins decisions
-    if (tid < NEAREST_TILE) {
+#if defined(SFM_ABLATE_NEAREST_UPTO) && SFM_ABLATE_NEAREST_UPTO == 1
+  return;   // diagnostic build: the scan of the segment counts alone
+#endif
+  unsigned long long needed = 0;   // entries whose distance this wavefront's lanes asked for (the same in all of its lanes)
+  for (uint32_t t0 = blockIdx.x * NEAREST_SUPER; t0 < total; t0 += gridDim.x * NEAREST_SUPER) {
+    // one lane per entry, 256 entries at once: the bins decisions.  (Three dependent trips to memory --
+    // list entry, histograms, rows -- are what a tile costs; taking the first two for four tiles
+    // together and sending a tile's row loads off before the tile before it is summed leaves about one
+    // trip per tile.)
+    {
       uint32_t i = 0, j = 0, f = 0;
       const uint32_t k = t0 + (uint32_t)tid;
-      if (k < total) {
+      if (tid < NEAREST_SUPER && k < total) {
         // the segment that holds entry k: the last one that starts at or before k
         int lo = 0, hi = segments - 1;
         while (lo < hi) {
@@ -684,67 +697,88 @@ __global__ __launch_bounds__(256, 4) void k_ch_nearest(const CascadePair* __rest
         i = entry.x;
         j = entry.y & ((1u << LIST_H_SHIFT) - 1u);
         const uint32_t h = entry.y >> LIST_H_SHIFT;
+        // A descriptor's result slot says that the descriptor was touched (the compaction puts such
+        // slots back to zero) either through its state or through its running minimum: the state is
+        // only stored where this entry will not leave a distance.
         const uint32_t state_a = take_state(P.hist_a + (size_t)i * HIST_WORDS);
-        P.res_a[(size_t)i * RES_WORDS + RES_STATE] = state_a;
         if (inside_taken_bins(state_a, h)) f |= 1u;
+        else P.res_a[(size_t)i * RES_WORDS + RES_STATE] = state_a;
         if (both_directions) {
           const uint32_t state_b = take_state(P.hist_b + (size_t)j * HIST_WORDS);
-          P.res_b[(size_t)j * RES_WORDS + RES_STATE] = state_b;
           if (inside_taken_bins(state_b, h)) f |= 2u;
+          else P.res_b[(size_t)j * RES_WORDS + RES_STATE] = state_b;
         }
         if (f == 0) i = j = 0;   // no distance needed: the loads below go to row 0 and are not used
       }
-      ent_i[tid] = i;
-      ent_j[tid] = j;
-      ent_f[tid] = f;
+      if (tid < NEAREST_SUPER) {
+        ent_i[tid] = i;
+        ent_j[tid] = j;
+        ent_f[tid] = f;
+      }
       if (work) needed += (unsigned long long)__popcll(__ballot(f != 0));   // statistics only
     }
     __syncthreads();
+#if defined(SFM_ABLATE_NEAREST_UPTO) && SFM_ABLATE_NEAREST_UPTO == 2
+    continue;   // diagnostic build: + the bins decisions
+#endif
+    const uint32_t left = total - t0;
+    const int tiles = (int)((left < (uint32_t)NEAREST_SUPER ? left : (uint32_t)NEAREST_SUPER) + NEAREST_TILE - 1) / NEAREST_TILE;
     // 32 lanes per row: eight entries per half-wavefront, all sixteen loads on their way before the
     // first is used (no branches: an entry that needs no distance reads row 0)
-    {
-#pragma clang fp contract(off)
-      const int half = lane >> 5, jj = lane & 31;
-      float4 a[8], b[8];
+    const int half = lane >> 5, jj = lane & 31;
+    float4 a[8], b[8];
+    auto issue_loads = [&](int tile) {
 #pragma unroll
       for (int it = 0; it < 8; it++) {
-        const int e = wv * 16 + half * 8 + it;
+        const int e = tile * NEAREST_TILE + wv * 16 + half * 8 + it;
         a[it] = reinterpret_cast<const float4*>(P.da + (size_t)ent_i[e] * DIM)[jj];
         b[it] = reinterpret_cast<const float4*>(P.db + (size_t)ent_j[e] * DIM)[jj];
       }
-#pragma unroll
-      for (int it = 0; it < 8; it++) {
-        const int e = wv * 16 + half * 8 + it;
-        float4 d;
-        d.x = a[it].x - b[it].x; d.y = a[it].y - b[it].y; d.z = a[it].z - b[it].z; d.w = a[it].w - b[it].w;
-        d.x = d.x * d.x; d.y = d.y * d.y; d.z = d.z * d.z; d.w = d.w * d.w;
-        *reinterpret_cast<float4*>(sq + e * NEAREST_SQ_STRIDE + 4 * jj) = d;
-      }
-    }
-    __syncthreads();
-    if (tid < NEAREST_TILE && ent_f[tid] != 0) {
+    };
+    issue_loads(0);
+    for (int tile = 0; tile < tiles; tile++) {
+      {
 #pragma clang fp contract(off)
-      const float4* s4 = reinterpret_cast<const float4*>(sq + tid * NEAREST_SQ_STRIDE);
-      float sum = 0.0f;
-#pragma unroll 8
-      for (int k = 0; k < DIM / 4; k++) {
-        const float4 v = s4[k];
-        sum = sum + v.x;
-        sum = sum + v.y;
-        sum = sum + v.z;
-        sum = sum + v.w;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const int e = wv * 16 + half * 8 + it;
+          float4 d;
+          d.x = a[it].x - b[it].x; d.y = a[it].y - b[it].y; d.z = a[it].z - b[it].z; d.w = a[it].w - b[it].w;
+          d.x = d.x * d.x; d.y = d.y * d.y; d.z = d.z * d.z; d.w = d.w * d.w;
+          *reinterpret_cast<float4*>(sq + e * NEAREST_SQ_STRIDE + 4 * jj) = d;
+        }
       }
-      // (a - b)^2 and (b - a)^2 are the same float: one distance serves both directions
-      const uint32_t i = ent_i[tid], j = ent_j[tid], f = ent_f[tid];
-      const unsigned long long hi = (unsigned long long)__float_as_uint(sqrtf(sum)) << 32;
-      if (f & 1u) atomicMax(reinterpret_cast<unsigned long long*>(P.res_a + (size_t)i * RES_WORDS + RES_BEST), ~(hi | j));
-      if (f & 2u) atomicMax(reinterpret_cast<unsigned long long*>(P.res_b + (size_t)j * RES_WORDS + RES_BEST), ~(hi | i));
+      if (tile + 1 < tiles) issue_loads(tile + 1);   // on their way while this tile is summed
+      __syncthreads();
+      const int e = tile * NEAREST_TILE + tid;
+#if defined(SFM_ABLATE_NEAREST_UPTO) && SFM_ABLATE_NEAREST_UPTO == 3
+      if (tid < NEAREST_TILE && ent_f[e] == 77u) {   // diagnostic build: + the rows and their squares, no sums
+#else
+      if (tid < NEAREST_TILE && ent_f[e] != 0) {
+#endif
+#pragma clang fp contract(off)
+        const float4* s4 = reinterpret_cast<const float4*>(sq + tid * NEAREST_SQ_STRIDE);
+        float sum = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < DIM / 4; k++) {
+          const float4 v = s4[k];
+          sum = sum + v.x;
+          sum = sum + v.y;
+          sum = sum + v.z;
+          sum = sum + v.w;
+        }
+        // (a - b)^2 and (b - a)^2 are the same float: one distance serves both directions
+        const uint32_t i = ent_i[e], j = ent_j[e], f = ent_f[e];
+        const unsigned long long hi = (unsigned long long)__float_as_uint(sqrtf(sum)) << 32;
+        if (f & 1u) atomicMax(reinterpret_cast<unsigned long long*>(P.res_a + (size_t)i * RES_WORDS + RES_BEST), ~(hi | j));
+        if (f & 2u) atomicMax(reinterpret_cast<unsigned long long*>(P.res_b + (size_t)j * RES_WORDS + RES_BEST), ~(hi | i));
+      }
+      __syncthreads();   // the squares are free again (and, after the last tile, the entries)
     }
-    __syncthreads();   // the tile's arrays are free again
   }
   // one of WORK_SLOTS counters (a single one would serialise the launch's atomics); they lie behind the
   // walk's WORK_SLOTS counters, which start two words after work[0]
-  if (work && tid == 0 && needed)
+  if (work && lane == 0 && needed)
     atomicAdd(work + 2 + WORK_SLOTS + ((blockIdx.z * gridDim.x + blockIdx.x) & (WORK_SLOTS - 1)), needed);
 }
 
@@ -802,16 +836,18 @@ __global__ __launch_bounds__(CH_COMPACT_THREADS) void k_ch_compact(const Cascade
     bool keep = false, fwd = false;
     if (i < P.na) {
       uint32_t* ra = P.res_a + (size_t)i * RES_WORDS;
-      const uint4 t = *reinterpret_cast<const uint4*>(ra);     // state, -, best (inverted) low, high
-      if (t.x != 0) clear_query(P.hist_a + (size_t)i * HIST_WORDS, ra);   // only this thread ever reads query i
-      if (t.x >= STATE_MATCH) {
+      // state, -, best (inverted) low, high.  Touched: a state or a minimum; matched: a minimum (distances
+      // are only ever folded into a descriptor whose state says "match")
+      const uint4 t = *reinterpret_cast<const uint4*>(ra);
+      if ((t.x | t.z | t.w) != 0) clear_query(P.hist_a + (size_t)i * HIST_WORDS, ra);   // only this thread ever reads query i
+      if ((t.z | t.w) != 0) {
         fwd = true;
         j = (int)~t.z;
         d = __uint_as_float(~t.w);
         keep = true;
         if (cross_check) {
           const uint4 u = *reinterpret_cast<const uint4*>(P.res_b + (size_t)j * RES_WORDS);
-          keep = u.x >= STATE_MATCH && (int)~u.z == i;
+          keep = (u.z | u.w) != 0 && (int)~u.z == i;
         }
       }
     }
@@ -841,7 +877,8 @@ __global__ __launch_bounds__(CH_COMPACT_THREADS) void k_ch_compact(const Cascade
   if (cross_check) {
     for (int q = tid; q < P.nb; q += CH_COMPACT_THREADS) {
       uint32_t* rb = P.res_b + (size_t)q * RES_WORDS;
-      if (rb[RES_STATE] != 0) clear_query(P.hist_b + (size_t)q * HIST_WORDS, rb);
+      const uint4 u = *reinterpret_cast<const uint4*>(rb);
+      if ((u.x | u.z | u.w) != 0) clear_query(P.hist_b + (size_t)q * HIST_WORDS, rb);
     }
   }
   if (tid == 0) {

@@ -17,7 +17,10 @@ using namespace sfm_host;
 namespace {
 
 constexpr size_t PROJ_FLOATS = (size_t)PROJ_MEAN_AT + DIM;   // projection rows (transposed, padded), then the mean
-constexpr int MAX_PAIRS_PER_BATCH = 1024;
+#ifndef SFM_CASCADE_BATCH_PAIRS   // (overridden in timing experiments: tools/build_variant.sh)
+#define SFM_CASCADE_BATCH_PAIRS 1024
+#endif
+constexpr int MAX_PAIRS_PER_BATCH = SFM_CASCADE_BATCH_PAIRS;
 constexpr size_t SLOT_BYTES_PER_BATCH = (size_t)2 << 30;
 constexpr size_t LIST_BYTES_PER_BATCH = (size_t)1 << 30;
 
@@ -437,7 +440,7 @@ int sfm_hip_cascade_match_pairs(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32
       hipLaunchKernelGGL(k_ch_take_all, dim3(FALLBACK_BLOCKS, cross_check ? 2 : 1, (unsigned)count), dim3(256), 0, st, dp,
                          ctx->cascade_counters);
       HIP_TRY(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_ch_walk_nearest, dim3(FALLBACK_BLOCKS, GROUPS, (unsigned)count), dim3(WALK_THREADS), 0, st, dp,
+      hipLaunchKernelGGL(k_ch_walk_nearest, dim3(FALLBACK_BLOCKS, 1, (unsigned)count), dim3(WALK_THREADS), 0, st, dp,
                          both);
       HIP_TRY(ctx, hipGetLastError());
     } else {
