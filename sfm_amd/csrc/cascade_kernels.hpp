@@ -94,7 +94,10 @@ struct alignas(16) HashMeta {
 // Per-query work space of one pair and direction, all zero between batches: a histogram row of 12
 // words (bins 0..10 of close candidates by Hamming distance, one word unused) and, in an array of
 // its own because the compaction reads nothing else, a result of 4 words.
-constexpr int HIST_WORDS = 12;
+#ifndef SFM_HIST_WORDS   // (overridden in timing experiments: tools/build_variant.sh)
+#define SFM_HIST_WORDS 12
+#endif
+constexpr int HIST_WORDS = SFM_HIST_WORDS;
 constexpr int RES_WORDS = 4;
 constexpr int RES_STATE = 0;       // 1: seen, but no match; 2 + h: match, bins 0..h taken; 0: not seen, or not stored (k_ch_nearest
                                    // stores it only where no distance will mark the slot: touched = state or minimum non-zero)

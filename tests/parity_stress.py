@@ -1,5 +1,5 @@
 """Randomised parity run of the HIP path against the CPU oracle, beyond what the test suite holds:
-    python tools/parity_stress.py [--path brute|batch|cascade|geometry] [--seconds 90] [--seed 1]
+    python tests/parity_stress.py [--path brute|batch|cascade|geometry] [--seconds 90] [--seed 1]
 brute (the default): random image sizes and four kinds of descriptors (RootSIFT-like rows with planted near-copies, Gaussian
 rows, rows on a small integer lattice -- full of exact ties --, crowds of near-duplicates), both distance
 engines, with and without cross-check, ratios near and far from 0.8.  Indices and distance bits must be
@@ -199,12 +199,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=90.0)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
-    if a.path == "batch":
-        return run_batch(a)
-    if a.path == "cascade":
-        return run_cascade(a)
-    if a.path == "geometry":
-        return run_geometry(a)
+    {"brute": run_brute, "batch": run_batch, "cascade": run_cascade, "geometry": run_geometry}[a.path](a)
+
+
+def run_brute(a):
     rng = np.random.default_rng(a.seed)
     m = sfm_amd.Matcher(0)
     t0 = time.perf_counter()

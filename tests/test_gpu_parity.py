@@ -648,7 +648,7 @@ def test_crowds_of_near_equal_distances_around_the_ratio_threshold(matcher, seed
 
 
 def test_four_rows_in_one_column_list_with_tied_keys(matcher):
-    """Found by tools/parity_stress.py: a first image of four rows, three of them within 3e-5 of each
+    """Found by tests/parity_stress.py: a first image of four rows, three of them within 3e-5 of each
     other in distance from a column -- one value to an 8-bit key -- so that the lane's two-entry column
     list drops one of them by index, and it was the nearest.  A small image is no reason to skip the
     completeness proof (tests/golden/near_tie_4x3.npz holds the inputs as they were drawn)."""
