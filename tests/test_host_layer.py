@@ -17,7 +17,8 @@ HOST = os.path.join(ROOT, "sfm_amd", "host")
 @pytest.fixture(scope="session")
 def cpu_driver(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("host") / "cpu_driver")
-    cmd = ["g++", "-O2", "-std=c++17", "-I", HOST, "-o", exe, os.path.join(ROOT, "tests", "host", "cpu_driver.cc"),
+    # SFM_TEST_CXXFLAGS: extra compiler flags for this program, e.g. "-fsanitize=address,undefined -g"
+    cmd = ["g++", "-O2", "-std=c++17"] + os.environ.get("SFM_TEST_CXXFLAGS", "").split() + ["-I", HOST, "-o", exe, os.path.join(ROOT, "tests", "host", "cpu_driver.cc"),
            os.path.join(HOST, "exhaustive_pair_builder.cc"), os.path.join(HOST, "sfm_data_io.cc"),
            os.path.join(HOST, "sfm_data_json.cc"),
            "-x", "c", "-std=c11", "-ffp-contract=off", os.path.join(ROOT, "oracle", "bf_oracle.c"), "-lm", "-pthread"]
