@@ -170,7 +170,9 @@ def cascade_reference_projection():
 def _sorted_pairs(pairs):
     """The pair list as the reference walks it: a std::set of (first, second), ascending."""
     p = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
-    return np.ascontiguousarray(sorted(set(map(tuple, p.tolist()))), dtype=np.int64).reshape(-1, 2)
+    if len(p) == 0:
+        return p
+    return np.ascontiguousarray(np.unique(p, axis=0))     # unique rows, in lexicographic order
 
 
 def cascade_image_order(pairs):

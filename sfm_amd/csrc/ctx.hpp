@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -21,8 +22,11 @@ struct Image {
   float* norms = nullptr;   // [n_pad + 2]: squared norms, then the largest norm and the largest magnitude
   float* scale = nullptr;   // {2^e, 2^-e} of the split planes
   int32_t n = 0, n_pad = 0;
-  // cascade-hash state (sfm_hip_cascade_hash_images): one allocation holding the hash records in
-  // image order, the six copies sorted by bucket, and the bucket offsets
+  // cascade-hash state (sfm_hip_cascade_hash_images): the hash records in image order, the six
+  // copies sorted by bucket, and the bucket offsets, in this image's part (hash_block) of an
+  // allocation that the images hashed by one call share (an allocation per image costs more than
+  // hashing the image); it is freed when the last of them lets go of it
+  std::shared_ptr<void> hash_owner;
   void* hash_block = nullptr;
   void* hash_recs = nullptr;      // [n] records of 32 bytes, image order
   // per group, sorted by that group's bucket id, then by index ([6][n] each):
@@ -136,7 +140,9 @@ struct sfm_hip_ctx {
   // cascade-hash matcher
   float* cascade_projection = nullptr;   // device: [128 + 60][128] projection rows, then the 128-float mean
   bool cascade_has_projection = false;
+  bool cascade_projection_is_reference = false;   // ... and it is the reference's, put there by sfm_hip_cascade_prepare
   unsigned long long* cascade_counters = nullptr;   // device: {pairs whose list overflowed, scratch for checks}
+  sfm_host::DevBuf cascade_scratch;                 // grow-only: the image table and the sums of sfm_hip_cascade_column_sums
   std::vector<hipEvent_t> cascade_timing;   // five events per timed cascade match batch (the middle three only per kernel)
   std::vector<char> cascade_timing_per_kernel;   // per timed batch: were the middle three recorded
   sfm_hip_cascade_stats cascade_stats{};
@@ -232,7 +238,7 @@ inline int ensure_stage(sfm_hip_ctx* ctx, Lane& L, int slot, size_t bytes) {
 }
 
 inline void free_image_hashes(Image& im) {
-  if (im.hash_block) (void)hipFree(im.hash_block);
+  im.hash_owner.reset();
   im.hash_block = nullptr;
   im.hash_recs = nullptr;
   im.hash_glo = nullptr;

@@ -256,6 +256,7 @@ void sfm_hip_ctx_destroy(sfm_hip_ctx* ctx) {
   if (ctx->rescanned_dev) (void)hipFree(ctx->rescanned_dev);
   if (ctx->cascade_projection) (void)hipFree(ctx->cascade_projection);
   if (ctx->cascade_counters) (void)hipFree(ctx->cascade_counters);
+  if (ctx->cascade_scratch.p) (void)hipFree(ctx->cascade_scratch.p);
   for (DevBuf& b : ctx->geometry_buffers)
     if (b.p) (void)hipFree(b.p);
   if (ctx->geometry_readback) (void)hipStreamDestroy(ctx->geometry_readback);

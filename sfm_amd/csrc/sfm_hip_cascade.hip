@@ -34,13 +34,6 @@ constexpr int FALLBACK_BLOCKS = 8;   // workgroups striding one pair's queries /
 // of the batch (k_ch_walk).
 int walk_blocks(int max_na) { return std::max(1, (max_na + WALK_THREADS - 1) / WALK_THREADS); }
 
-struct Scratch {   // a device allocation that lives for one call
-  void* p = nullptr;
-  ~Scratch() {
-    if (p) (void)hipFree(p);
-  }
-};
-
 int find_images(sfm_hip_ctx* ctx, const int64_t* ids, int32_t n, std::vector<Image*>& out) {
   out.clear();
   for (int32_t k = 0; k < n; k++) {
@@ -111,6 +104,7 @@ int sfm_hip_cascade_set_projection(sfm_hip_ctx* ctx, const float* primary, const
   if (int rc = sync_all(ctx)) return rc;
   HIP_TRY(ctx, hipMemcpy(ctx->cascade_projection, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
   ctx->cascade_has_projection = true;
+  ctx->cascade_projection_is_reference = false;   // (sfm_hip_cascade_prepare sets it after its own call)
   return SFM_HIP_OK;
 }
 
@@ -124,14 +118,17 @@ int sfm_hip_cascade_column_sums(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
   if (int rc = find_images(ctx, image_ids, n_images, ims)) return rc;
   std::vector<ImageRef> refs((size_t)n_images);
   for (int32_t k = 0; k < n_images; k++) refs[(size_t)k] = ImageRef{ims[(size_t)k]->d, ims[(size_t)k]->n, 0};
-  Scratch table, sums;
-  HIP_TRY(ctx, hipMalloc(&table.p, refs.size() * sizeof(ImageRef)));
-  HIP_TRY(ctx, hipMalloc(&sums.p, (size_t)n_images * DIM * sizeof(float)));
+  // table | sums, in a buffer the context keeps (allocating and freeing per call costs as much as the kernel;
+  // every use of the buffer is on the upload stream and ends with the host waiting for it)
+  const size_t table_bytes = align_up(refs.size() * sizeof(ImageRef), 256);
+  if (int rc = ensure(ctx, ctx->lanes[0], ctx->cascade_scratch, table_bytes + (size_t)n_images * DIM * sizeof(float))) return rc;
+  void* table = ctx->cascade_scratch.p;
+  float* sums = (float*)((char*)ctx->cascade_scratch.p + table_bytes);
   hipStream_t st = ctx->upload_stream;
-  HIP_TRY(ctx, hipMemcpyAsync(table.p, refs.data(), refs.size() * sizeof(ImageRef), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_ch_colsum, dim3((unsigned)n_images), dim3(DIM), 0, st, (const ImageRef*)table.p, (float*)sums.p);
+  HIP_TRY(ctx, hipMemcpyAsync(table, refs.data(), refs.size() * sizeof(ImageRef), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_ch_colsum, dim3((unsigned)n_images), dim3(DIM), 0, st, (const ImageRef*)table, sums);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(out_sums, sums.p, (size_t)n_images * DIM * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(out_sums, sums, (size_t)n_images * DIM * sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return SFM_HIP_OK;
 }
@@ -159,78 +156,87 @@ int sfm_hip_cascade_hash_images(sfm_hip_ctx* ctx, const int64_t* image_ids, int3
   if (rehash)
     if (int rc = sync_all(ctx)) return rc;
   hipStream_t st = ctx->upload_stream;
-  // New hashes are built in blocks of their own and become the images' hashes only after the
-  // kernels that fill them have finished; on any failure the new blocks are freed and the images
-  // keep what they had (valid older hashes, or none).
-  struct Fresh {
-    void* block = nullptr;
-    size_t recs_bytes = 0, half_bytes = 0, bkt_bytes = 0, meta_bytes = 0;
+  // New hashes are built in an allocation of their own -- one for all images of the call, with the job
+  // table behind them -- and become the images' hashes only after the kernels that fill them have
+  // finished; on any failure it is freed and the images keep what they had (valid older hashes, or none).
+  struct Part {
+    size_t at = 0, recs_bytes = 0, half_bytes = 0, bkt_bytes = 0, meta_bytes = 0;
   };
-  std::vector<Fresh> fresh(ims.size());
+  std::vector<Part> parts(ims.size());
+  const size_t off_bytes = align_up((size_t)GROUPS * (BUCKETS + 1) * sizeof(int32_t), 256);
+  size_t total = 0;
+  for (size_t k = 0; k < ims.size(); k++) {
+    Part& f = parts[k];
+    const size_t n = std::max<size_t>((size_t)ims[k]->n, 1);
+    f.at = total;
+    f.recs_bytes = align_up(n * sizeof(HashRec), 256);
+    f.half_bytes = align_up(n * GROUPS * sizeof(uint2), 256);
+    f.bkt_bytes = align_up(n * GROUPS * sizeof(uint16_t), 256);
+    f.meta_bytes = align_up(n * GROUPS * sizeof(HashMeta), 256);
+    total += f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes + f.meta_bytes + off_bytes;
+  }
+  const size_t table_at = total;
+  total += align_up(ims.size() * sizeof(HashJob), 256);
+  void* raw = nullptr;
+  {
+    const hipError_t e = hipMalloc(&raw, total);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc hash records: ") + hipGetErrorString(e));
+    }
+  }
+  std::shared_ptr<void> owner(raw, [](void* p) { (void)hipFree(p); });
+  auto part_of = [&](size_t k, HashJob& j) {
+    const Part& f = parts[k];
+    char* at = (char*)raw + f.at;
+    j.recs = (HashRec*)at;
+    j.glo = (uint2*)(at + f.recs_bytes);
+    j.ghi = (uint2*)(at + f.recs_bytes + f.half_bytes);
+    j.gbkt = (uint16_t*)(at + f.recs_bytes + 2 * f.half_bytes);
+    j.gmeta = (HashMeta*)(at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes);
+    j.offsets = (int32_t*)(at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes + f.meta_bytes);
+  };
+  std::vector<HashJob> jobs(ims.size());
   auto build = [&]() -> int {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->cascade_projection + (size_t)PROJ_MEAN_AT, mean128, DIM * sizeof(float),
                                 hipMemcpyHostToDevice, st));
-    std::vector<HashJob> jobs;
     int blocks = 0;
     for (size_t k = 0; k < ims.size(); k++) {
-      const Image* im = ims[k];
-      Fresh& f = fresh[k];
-      const size_t n = std::max<size_t>((size_t)im->n, 1);
-      f.recs_bytes = align_up(n * sizeof(HashRec), 256);
-      f.half_bytes = align_up(n * GROUPS * sizeof(uint2), 256);
-      f.bkt_bytes = align_up(n * GROUPS * sizeof(uint16_t), 256);
-      f.meta_bytes = align_up(n * GROUPS * sizeof(HashMeta), 256);
-      const size_t off_bytes = align_up((size_t)GROUPS * (BUCKETS + 1) * sizeof(int32_t), 256);
-      const hipError_t e = hipMalloc(&f.block, f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes + f.meta_bytes + off_bytes);
-      if (e != hipSuccess) {
-        f.block = nullptr;
-        return fail(ctx, SFM_HIP_ERR_NOMEM, std::string("hipMalloc hash records: ") + hipGetErrorString(e));
-      }
-      char* at = (char*)f.block;
-      HashJob j;
-      j.d = im->d;
-      j.recs = (HashRec*)at;
-      j.glo = (uint2*)(at + f.recs_bytes);
-      j.ghi = (uint2*)(at + f.recs_bytes + f.half_bytes);
-      j.gbkt = (uint16_t*)(at + f.recs_bytes + 2 * f.half_bytes);
-      j.gmeta = (HashMeta*)(at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes);
-      j.offsets = (int32_t*)(at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes + f.meta_bytes);
-      j.n = im->n;
+      HashJob& j = jobs[k];
+      part_of(k, j);
+      j.d = ims[k]->d;
+      j.n = ims[k]->n;
       j.first_block = blocks;
-      blocks += (im->n + 63) / 64;
-      jobs.push_back(j);
+      blocks += (ims[k]->n + 63) / 64;
     }
-    Scratch table;
-    HIP_TRY(ctx, hipMalloc(&table.p, jobs.size() * sizeof(HashJob)));
-    HIP_TRY(ctx, hipMemcpyAsync(table.p, jobs.data(), jobs.size() * sizeof(HashJob), hipMemcpyHostToDevice, st));
+    const HashJob* table = (const HashJob*)((char*)raw + table_at);
+    HIP_TRY(ctx, hipMemcpyAsync((void*)table, jobs.data(), jobs.size() * sizeof(HashJob), hipMemcpyHostToDevice, st));
     if (blocks > 0) {
-      hipLaunchKernelGGL(k_ch_hash, dim3((unsigned)blocks), dim3(256), 0, st, (const HashJob*)table.p, (int)jobs.size(),
+      hipLaunchKernelGGL(k_ch_hash, dim3((unsigned)blocks), dim3(256), 0, st, table, (int)jobs.size(),
                          (const float*)ctx->cascade_projection);
       HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_ch_group, dim3(GROUPS, (unsigned)jobs.size()), dim3(64), 0, st, (const HashJob*)table.p);
+    hipLaunchKernelGGL(k_ch_group, dim3(GROUPS, (unsigned)jobs.size()), dim3(64), 0, st, table);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return SFM_HIP_OK;
   };
   if (const int rc = build()) {
-    (void)hipStreamSynchronize(st);   // nothing may still write into the blocks that are freed now
-    for (Fresh& f : fresh)
-      if (f.block) (void)hipFree(f.block);
+    (void)hipStreamSynchronize(st);   // nothing may still write into the allocation, which `owner` frees on return
     return rc;
   }
   for (size_t k = 0; k < ims.size(); k++) {
     Image* im = ims[k];
-    const Fresh& f = fresh[k];
+    const HashJob& j = jobs[k];
     free_image_hashes(*im);
-    char* at = (char*)f.block;
-    im->hash_block = f.block;
-    im->hash_recs = at;
-    im->hash_glo = at + f.recs_bytes;
-    im->hash_ghi = at + f.recs_bytes + f.half_bytes;
-    im->hash_gbkt = at + f.recs_bytes + 2 * f.half_bytes;
-    im->hash_gmeta = at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes;
-    im->hash_offsets = (int32_t*)(at + f.recs_bytes + 2 * f.half_bytes + f.bkt_bytes + f.meta_bytes);
+    im->hash_owner = owner;
+    im->hash_block = j.recs;
+    im->hash_recs = j.recs;
+    im->hash_glo = j.glo;
+    im->hash_ghi = j.ghi;
+    im->hash_gbkt = j.gbkt;
+    im->hash_gmeta = j.gmeta;
+    im->hash_offsets = j.offsets;
   }
   ctx->cascade_stats.images_hashed += (uint64_t)ims.size();
   return SFM_HIP_OK;
@@ -502,10 +508,15 @@ int sfm_hip_cascade_image_order(const int64_t* pair_ids, int32_t n_pairs, int64_
 int sfm_hip_cascade_prepare(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pairs, float* out_mean128) {
   if (!ctx) return fail(nullptr, SFM_HIP_ERR_INVALID, "ctx is null");
   if (n_pairs < 0 || (n_pairs > 0 && !pair_ids)) return fail(ctx, SFM_HIP_ERR_INVALID, "bad pair list");
-  std::vector<float> primary((size_t)CODE_BITS * DIM), secondary((size_t)GROUPS * GROUP_BITS * DIM);
-  int rc = sfm_hip_cascade_reference_projection(primary.data(), secondary.data());
-  if (rc == SFM_HIP_OK) rc = sfm_hip_cascade_set_projection(ctx, primary.data(), secondary.data());
-  if (rc != SFM_HIP_OK) return rc;
+  int rc = SFM_HIP_OK;
+  if (!ctx->cascade_projection_is_reference) {
+    // (24,064 normal deviates and an upload: half a millisecond, as much as hashing thirty images -- once per context)
+    std::vector<float> primary((size_t)CODE_BITS * DIM), secondary((size_t)GROUPS * GROUP_BITS * DIM);
+    rc = sfm_hip_cascade_reference_projection(primary.data(), secondary.data());
+    if (rc == SFM_HIP_OK) rc = sfm_hip_cascade_set_projection(ctx, primary.data(), secondary.data());
+    if (rc != SFM_HIP_OK) return rc;
+    ctx->cascade_projection_is_reference = true;
+  }
   std::vector<int64_t> ids((size_t)2 * (size_t)std::max(n_pairs, 1));
   int32_t n_ids = 0;
   if ((rc = sfm_hip_cascade_image_order(pair_ids, n_pairs, ids.data(), &n_ids))) return fail(ctx, rc, g_last_error);
