@@ -371,14 +371,14 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
 
 /* Counters of the geometric verification since context creation or the last reset.  The work
  * counters and the durations are collected only while profiling is enabled (sfm_hip_set_profiling):
- * every launch of 256 rounds is then bracketed with HIP events on the stream it runs on, one in
+ * every launch (256 rounds of every unfinished pair, later launches up to 2,048) is then bracketed with HIP events on the stream it runs on, one in
  * front of the fit, one between fit and count, one behind the count. */
 typedef struct {
   uint64_t calls;          /* calls of sfm_hip_geometry_verify_pairs */
   uint64_t pairs;          /* pairs with at least eight matches among them */
-  uint64_t timed_launches; /* launches (fit + count of up to 256 rounds of every unfinished pair) that were timed */
+  uint64_t timed_launches; /* launches (fit + count of 256 to 2,048 rounds of every unfinished pair) that were timed */
   uint64_t rounds;         /* RANSAC rounds those launches sampled, fitted and counted: more than the
-                              rounds the pairs report, since a launch works on 256 rounds of a pair at once
+                              rounds the pairs report, since a launch works on 256 or more rounds of a pair at once
                               and the rounds behind the pair's stopping point are discarded */
   uint64_t match_rounds;   /* (match, round) pairs the count measured: sum over those rounds of the pair's matches */
   double fit_ms;           /* summed duration of the timed launches' k_geo_fit */

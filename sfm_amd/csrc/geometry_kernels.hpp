@@ -5,7 +5,7 @@
 // (src/solver/fundamental_solver.cc:13-86) with EpipolarLineError (src/solver/fundamental_solver.hpp:59-78).
 //
 // The reference runs its rounds one after the other because the number of rounds shrinks as better
-// models turn up.  Here a launch evaluates 256 rounds of every unfinished pair at once (one thread per
+// models turn up.  Here a launch evaluates 256 rounds of every unfinished pair at once, later launches 512 to 2,048 (one thread per
 // round: sample and fit in one kernel, count in another), then one thread per pair replays the reference's bookkeeping over those
 // 256 results in round order -- which yields exactly what the sequential loop would, the rounds
 // past the stopping point being wasted work -- and the host launches again while any pair is unfinished.
@@ -47,7 +47,7 @@ struct GeoPair {
   GeoState* state;
   double* hyp_F;                   // [256][9] models of the current launch
   int32_t* hyp_idx;                // [256][8] the matches they were fitted to
-  uint32_t* hyp_count;             // [256] their inlier counts
+  uint32_t* hyp_count;             // [256] their inlier counts   (each of the three times the launch's runs of 256 rounds)
   uint8_t* flags;                  // [n] final classification
   uint32_t* n_inliers;
   int32_t n;
@@ -224,12 +224,12 @@ __device__ __forceinline__ bool epipolar_error_exceeds(double x, double y, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
-// 256 rounds of every unfinished pair, in two kernels because they want opposite things from the
+// 256 rounds (or a few runs of 256) of every unfinished pair, in two kernels because they want opposite things from the
 // register file: the fit keeps two matrices in registers and runs one wavefront per SIMD, the
 // count needs few registers and hides its divisions behind eight.
-//   k_geo_fit    thread = one round: sample, fit.  grid: (4, pairs), 64 threads.
+//   k_geo_fit    thread = one round: sample, fit.  grid: (4 * runs, pairs), 64 threads.
 //   k_geo_count  thread = one round, workgroup = the 256 rounds of a pair: the matches pass through
-//                LDS in tiles, every thread measures each of them against its model.  grid: (pairs).
+//                LDS in tiles, every thread measures each of them against its model.  grid: (pairs, runs).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HYP_THREADS) void k_geo_fit(const GeoPair* __restrict__ pairs, uint32_t first_round) {
 #pragma clang fp contract(off)
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(ROUNDS_PER_LAUNCH) void k_geo_count(const GeoPair* 
   const GeoPair P = pairs[blockIdx.x];
   const GeoState* st = P.state;
   if (st->done) return;
-  const uint32_t slot = threadIdx.x;
+  const uint32_t slot = blockIdx.y * ROUNDS_PER_LAUNCH + threadIdx.x;
   const bool live = first_round + slot < st->rounds_limit;   // the same rounds k_geo_fit worked on
   const int n = P.n;
   double F[9];
@@ -420,9 +420,11 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return v;
 }
 
+// A launch holds `chunks` runs of 256 rounds per pair (slots 0 .. 256 * chunks - 1); they are replayed one
+// after the other, the state handed on in registers, until the loop has stopped.
 // `work` (may be null): two counters that receive the rounds this launch's fit and count worked on
 // and the (match, round) pairs the count measured -- for the statistics, not for the result.
-__global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restrict__ pairs, int n_pairs,
+__global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restrict__ pairs, int n_pairs, int chunks,
                                                         uint32_t* __restrict__ unfinished,
                                                         unsigned long long* __restrict__ work) {
   static_assert(ROUNDS_PER_LAUNCH == 256, "four slots per lane");
@@ -431,73 +433,87 @@ __global__ __launch_bounds__(64) void k_geo_bookkeeping(const GeoPair* __restric
   const GeoPair P = pairs[p];
   GeoState* st = P.state;
   if (st->done) return;
-  const uint32_t limit0 = st->rounds_limit, done0 = st->rounds_done, best0 = st->best_count;
+  uint32_t limit = st->rounds_limit, done = st->rounds_done, best = st->best_count;
   const int l = threadIdx.x;
   const uint32_t NONE = 0xFFFFFFFFu;
-  if (work && l == 0 && limit0 > done0) {   // the launch started at round done0 and skipped rounds at or beyond limit0
-    const unsigned long long worked = min(limit0 - done0, (uint32_t)ROUNDS_PER_LAUNCH);
-    atomicAdd(work, worked);
-    atomicAdd(work + 1, worked * (unsigned long long)P.n);
-  }
-  uint32_t cnt[4], need[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) cnt[k] = P.hyp_count[4 * l + k];
-#pragma unroll
-  for (int k = 0; k < 4; k++) need[k] = cnt[k] <= (uint32_t)P.n ? P.rounds_needed[cnt[k]] : NONE;
-  // N on entry to every slot: limit0 and the needs of all earlier slots
-  uint32_t lane_min = min(min(need[0], need[1]), min(need[2], need[3]));
-  uint32_t incl = lane_min;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t v = __shfl_up(incl, o);
-    if (l >= o) incl = min(incl, v);
-  }
-  uint32_t entry = __shfl_up(incl, 1);
-  if (l == 0) entry = NONE;
-  entry = min(entry, limit0);
-  // first stop: event 2s = before slot s (N <= rounds so far), 2s + 1 = after slot s (all inliers)
-  uint32_t ev = NONE;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t slot = (uint32_t)(4 * l + k);
-    if (ev == NONE) {
-      if (!(entry > done0 + slot)) ev = 2 * slot;
-      else if (cnt[k] == (uint32_t)P.n) ev = 2 * slot + 1;
+  if (work && l == 0) {   // the launch started at round `done` and skipped rounds at or beyond `limit`
+    unsigned long long worked = 0;
+    for (int c = 0; c < chunks; c++) {
+      const uint32_t from = done + (uint32_t)(c * ROUNDS_PER_LAUNCH);
+      if (limit > from) worked += min(limit - from, (uint32_t)ROUNDS_PER_LAUNCH);
     }
-    entry = min(entry, need[k]);
-  }
-  const uint32_t first_ev = wave_min_u32(ev);
-  const bool stop_before = first_ev != NONE && (first_ev & 1u) == 0;
-  const bool stop_after = first_ev != NONE && (first_ev & 1u) != 0;
-  const uint32_t consumed = first_ev == NONE ? (uint32_t)ROUNDS_PER_LAUNCH : (stop_after ? first_ev / 2 + 1 : first_ev / 2);
-  const uint32_t lowered_by = stop_after ? consumed - 1 : consumed;   // the all-inlier slot leaves N alone
-  // N afterwards, and the largest count among the consumed slots at its first occurrence
-  uint32_t lim = NONE;
-  unsigned long long top = 0;   // count << 32 | (NONE - slot): larger count first, then the earlier slot
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t slot = (uint32_t)(4 * l + k);
-    if (slot < lowered_by) lim = min(lim, need[k]);
-    if (slot < consumed) {
-      const unsigned long long key = ((unsigned long long)cnt[k] << 32) | (unsigned long long)(NONE - slot);
-      top = key > top ? key : top;
+    if (worked) {
+      atomicAdd(work, worked);
+      atomicAdd(work + 1, worked * (unsigned long long)P.n);
     }
   }
-  lim = min(wave_min_u32(lim), limit0);
+  bool finished = false;
+  for (int c = 0; c < chunks && !finished; c++) {
+    const uint32_t limit0 = limit, done0 = done, best0 = best;
+    const uint32_t base = (uint32_t)(c * ROUNDS_PER_LAUNCH);
+    uint32_t cnt[4], need[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long u = __shfl_xor(top, o);
-    top = u > top ? u : top;
+    for (int k = 0; k < 4; k++) cnt[k] = P.hyp_count[base + 4 * l + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) need[k] = cnt[k] <= (uint32_t)P.n ? P.rounds_needed[cnt[k]] : NONE;
+    // N on entry to every slot: limit0 and the needs of all earlier slots
+    uint32_t lane_min = min(min(need[0], need[1]), min(need[2], need[3]));
+    uint32_t incl = lane_min;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (l >= o) incl = min(incl, v);
+    }
+    uint32_t entry = __shfl_up(incl, 1);
+    if (l == 0) entry = NONE;
+    entry = min(entry, limit0);
+    // first stop: event 2s = before slot s (N <= rounds so far), 2s + 1 = after slot s (all inliers)
+    uint32_t ev = NONE;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t slot = (uint32_t)(4 * l + k);
+      if (ev == NONE) {
+        if (!(entry > done0 + slot)) ev = 2 * slot;
+        else if (cnt[k] == (uint32_t)P.n) ev = 2 * slot + 1;
+      }
+      entry = min(entry, need[k]);
+    }
+    const uint32_t first_ev = wave_min_u32(ev);
+    const bool stop_before = first_ev != NONE && (first_ev & 1u) == 0;
+    const bool stop_after = first_ev != NONE && (first_ev & 1u) != 0;
+    const uint32_t consumed = first_ev == NONE ? (uint32_t)ROUNDS_PER_LAUNCH : (stop_after ? first_ev / 2 + 1 : first_ev / 2);
+    const uint32_t lowered_by = stop_after ? consumed - 1 : consumed;   // the all-inlier slot leaves N alone
+    // N afterwards, and the largest count among the consumed slots at its first occurrence
+    uint32_t lim = NONE;
+    unsigned long long top = 0;   // count << 32 | (NONE - slot): larger count first, then the earlier slot
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t slot = (uint32_t)(4 * l + k);
+      if (slot < lowered_by) lim = min(lim, need[k]);
+      if (slot < consumed) {
+        const unsigned long long key = ((unsigned long long)cnt[k] << 32) | (unsigned long long)(NONE - slot);
+        top = key > top ? key : top;
+      }
+    }
+    lim = min(wave_min_u32(lim), limit0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long u = __shfl_xor(top, o);
+      top = u > top ? u : top;
+    }
+    const uint32_t top_count = (uint32_t)(top >> 32), top_slot = NONE - (uint32_t)(top & 0xFFFFFFFFull);
+    const bool replaced = consumed > 0 && top_count > best0;
+    const uint32_t done_rounds = done0 + consumed;
+    finished = stop_before || stop_after || !(lim > done_rounds);
+    if (replaced && l < 9) st->best_F[l] = P.hyp_F[(size_t)(base + top_slot) * 9 + l];
+    limit = lim;
+    done = done_rounds;
+    best = replaced ? top_count : best0;
   }
-  const uint32_t top_count = (uint32_t)(top >> 32), top_slot = NONE - (uint32_t)(top & 0xFFFFFFFFull);
-  const bool replaced = consumed > 0 && top_count > best0;
-  const uint32_t done_rounds = done0 + consumed;
-  const bool finished = stop_before || stop_after || !(lim > done_rounds);
-  if (replaced && l < 9) st->best_F[l] = P.hyp_F[(size_t)top_slot * 9 + l];
   if (l == 0) {
-    st->rounds_limit = lim;
-    st->rounds_done = done_rounds;
-    st->best_count = replaced ? top_count : best0;
+    st->rounds_limit = limit;
+    st->rounds_done = done;
+    st->best_count = best;
     st->done = finished ? 1u : 0u;
     if (!finished) atomicAdd(unfinished, 1u);
   }

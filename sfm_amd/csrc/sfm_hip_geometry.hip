@@ -15,6 +15,9 @@ using namespace sfm_host;
 
 namespace {
 
+// Device memory a call may spend on the models of one launch (27,648 bytes per pair and run of 256 rounds)
+constexpr size_t HYP_BYTES_BUDGET = (size_t)1 << 30;
+
 // One of the context's grow-only buffers, at least `bytes` large.  The call is blocking and runs on
 // one stream, so nothing queued earlier can still be using the old allocation.
 int grown(sfm_hip_ctx* ctx, int which, size_t bytes, void** out) {
@@ -96,9 +99,16 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   if ((rc = grown(ctx, 1, (size_t)total * 16, &d_rhs.p))) return rc;
   if ((rc = grown(ctx, 2, tables.size() * 4, &d_tables.p))) return rc;
   if ((rc = grown(ctx, 3, (size_t)n_live * sizeof(GeoState), &d_state.p))) return rc;
-  if ((rc = grown(ctx, 4, (size_t)n_live * ROUNDS_PER_LAUNCH * 9 * sizeof(double), &d_hyp_F.p))) return rc;
-  if ((rc = grown(ctx, 5, (size_t)n_live * ROUNDS_PER_LAUNCH * SAMPLE * 4, &d_hyp_idx.p))) return rc;
-  if ((rc = grown(ctx, 6, (size_t)n_live * ROUNDS_PER_LAUNCH * 4, &d_hyp_count.p))) return rc;
+  // A launch evaluates 256 rounds of every unfinished pair, or several runs of 256 ("chunks") once most
+  // pairs have finished -- a launch takes a round's serial time whatever the number of rounds in it,
+  // so the pairs that need many rounds get them in few launches: 1, 2, 4, 8 runs, then one at a time.
+  // What a launch may hold is bounded by the memory of its models: 27,648 bytes per pair and run.
+  const size_t run_bytes = (size_t)ROUNDS_PER_LAUNCH * (9 * sizeof(double) + SAMPLE * 4 + 4);
+  const int max_chunks = (int)std::max<size_t>(1, std::min<size_t>(8, HYP_BYTES_BUDGET / ((size_t)n_live * run_bytes)));
+  const size_t slots = (size_t)max_chunks * ROUNDS_PER_LAUNCH;   // per pair
+  if ((rc = grown(ctx, 4, (size_t)n_live * slots * 9 * sizeof(double), &d_hyp_F.p))) return rc;
+  if ((rc = grown(ctx, 5, (size_t)n_live * slots * SAMPLE * 4, &d_hyp_idx.p))) return rc;
+  if ((rc = grown(ctx, 6, (size_t)n_live * slots * 4, &d_hyp_count.p))) return rc;
   if ((rc = grown(ctx, 7, (size_t)total, &d_flags.p))) return rc;
   if ((rc = grown(ctx, 8, (size_t)n_live * 4, &d_counts.p))) return rc;
   if ((rc = grown(ctx, 9, (size_t)n_live * sizeof(GeoPair), &d_pairs.p))) return rc;
@@ -128,9 +138,9 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
     g.rhs = (const double*)d_rhs.p + 2 * at;
     g.rounds_needed = (const uint32_t*)d_tables.p + table_at.at(n);
     g.state = (GeoState*)d_state.p + k;
-    g.hyp_F = (double*)d_hyp_F.p + (size_t)k * ROUNDS_PER_LAUNCH * 9;
-    g.hyp_idx = (int32_t*)d_hyp_idx.p + (size_t)k * ROUNDS_PER_LAUNCH * SAMPLE;
-    g.hyp_count = (uint32_t*)d_hyp_count.p + (size_t)k * ROUNDS_PER_LAUNCH;
+    g.hyp_F = (double*)d_hyp_F.p + (size_t)k * slots * 9;
+    g.hyp_idx = (int32_t*)d_hyp_idx.p + (size_t)k * slots * SAMPLE;
+    g.hyp_count = (uint32_t*)d_hyp_count.p + (size_t)k * slots;
     g.flags = (uint8_t*)d_flags.p + at;
     g.n_inliers = (uint32_t*)d_counts.p + k;
     g.n = (int32_t)n;
@@ -170,17 +180,23 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
     HIP_TRY(ctx, hipEventRecord(e, st));
     return SFM_HIP_OK;
   };
+  constexpr int TOTAL_CHUNKS = MAX_ROUNDS / ROUNDS_PER_LAUNCH;
+  int chunks_queued = 0;   // runs of 256 rounds in the launches queued so far
   auto queue_launch = [&](int k) -> int {
-    const uint32_t first = (uint32_t)k * ROUNDS_PER_LAUNCH;
+    static const int schedule[4] = {1, 2, 4, 8};
+    const int chunks = std::min(std::min(k < 4 ? schedule[k] : 1, max_chunks), TOTAL_CHUNKS - chunks_queued);
+    const uint32_t first = (uint32_t)chunks_queued * ROUNDS_PER_LAUNCH;
+    chunks_queued += chunks;
     int mrc;
     if ((mrc = mark())) return mrc;
-    hipLaunchKernelGGL(k_geo_fit, dim3(ROUNDS_PER_LAUNCH / HYP_THREADS, (unsigned)n_live), dim3(HYP_THREADS), 0, st, dp, first);
+    hipLaunchKernelGGL(k_geo_fit, dim3((unsigned)(chunks * (ROUNDS_PER_LAUNCH / HYP_THREADS)), (unsigned)n_live), dim3(HYP_THREADS), 0, st,
+                       dp, first);
     HIP_TRY(ctx, hipGetLastError());
     if ((mrc = mark())) return mrc;
-    hipLaunchKernelGGL(k_geo_count, dim3((unsigned)n_live), dim3(ROUNDS_PER_LAUNCH), 0, st, dp, first);
+    hipLaunchKernelGGL(k_geo_count, dim3((unsigned)n_live, (unsigned)chunks), dim3(ROUNDS_PER_LAUNCH), 0, st, dp, first);
     HIP_TRY(ctx, hipGetLastError());
     if ((mrc = mark())) return mrc;
-    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)n_live), dim3(64), 0, st, dp, n_live, (uint32_t*)d_unfinished.p + k,
+    hipLaunchKernelGGL(k_geo_bookkeeping, dim3((unsigned)n_live), dim3(64), 0, st, dp, n_live, chunks, (uint32_t*)d_unfinished.p + k,
                        d_work);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->geometry_events[k], st));
@@ -188,12 +204,13 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
   };
   if ((rc = queue_launch(0))) return rc;
   for (int k = 0; k < MAX_LAUNCHES; k++) {
-    if (k + 1 < MAX_LAUNCHES && (rc = queue_launch(k + 1))) return rc;
+    const bool more = chunks_queued < TOTAL_CHUNKS;
+    if (more && (rc = queue_launch(k + 1))) return rc;
     uint32_t unfinished = 0;
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->geometry_readback, ctx->geometry_events[k], 0));
     HIP_TRY(ctx, hipMemcpyAsync(&unfinished, (uint32_t*)d_unfinished.p + k, 4, hipMemcpyDeviceToHost, ctx->geometry_readback));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->geometry_readback));
-    if (unfinished == 0) break;
+    if (unfinished == 0 || !more) break;
   }
   hipLaunchKernelGGL(k_geo_classify, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_live), dim3(256), 0, st, dp);
   HIP_TRY(ctx, hipGetLastError());

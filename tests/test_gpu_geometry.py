@@ -103,3 +103,22 @@ def test_statistics_count_the_work_of_timed_calls(matcher):
     matcher.geometry_verify_pairs(sets, seed=2)
     again = matcher.geometry_stats()
     assert again["calls"] == 2 and again["rounds"] == st["rounds"] and again["timed_launches"] == st["timed_launches"]
+
+
+@pytest.mark.parametrize("n_pairs", [6000, 40000])
+def test_calls_of_many_pairs_get_fewer_rounds_per_launch(matcher, n_pairs):
+    """A launch holds as many runs of 256 rounds per pair as a fixed amount of device memory allows: eight for
+    a few thousand pairs, six for 6,000, one for 40,000.  The result does not depend on it: a sample of
+    the pairs against the oracle, and the first pairs against a call of their own (eight runs)."""
+    rng = np.random.default_rng(n_pairs)
+    base = [synth.make_two_view_matches(int(rng.integers(8, 40)), float(rng.uniform(0.3, 1.0)), seed=900 + k, noise=0.5)[:2]
+            for k in range(50)]
+    sets = [base[k % 50] for k in range(n_pairs)]
+    got = matcher.geometry_verify_pairs(sets, seed=17)
+    for k in list(range(0, n_pairs, n_pairs // 23)) + [n_pairs - 1]:
+        l, r = sets[k]
+        _same(got[k], geometry.compute_fundamental(l, r, seed=17, pair=k))
+    alone = matcher.geometry_verify_pairs(sets[:60], seed=17)
+    for a, b in zip(alone, got[:60]):
+        _same(a, b)
+    assert max(g[3] for g in got) > 1024      # some pairs go through several launches
