@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--path", choices=("brute", "batch", "cascade", "geometry"), default="brute")
     ap.add_argument("--seconds", type=float, default=90.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-log2", type=float, default=11.7, help="brute: image sizes are 2^u, u uniform in [0, this]")
     a = ap.parse_args()
     {"brute": run_brute, "batch": run_batch, "cascade": run_cascade, "geometry": run_geometry}[a.path](a)
 
@@ -209,7 +210,7 @@ def run_brute(a):
     n = 0
     rescans = 0
     while time.perf_counter() - t0 < a.seconds:
-        na, nb = (int(2 ** rng.uniform(0, 11.7)) for _ in range(2))
+        na, nb = (int(2 ** rng.uniform(0, a.max_log2)) for _ in range(2))
         kind = int(rng.integers(0, 4))
         A, B = make(kind, na, nb, rng)
         ratio = float(rng.choice([0.8, 0.8, 0.8, 0.6, 0.95, 1.0]))

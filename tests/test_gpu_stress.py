@@ -22,7 +22,7 @@ def _tool():
 @pytest.mark.parametrize("path,seed", [("brute", 101), ("batch", 102), ("cascade", 103), ("geometry", 104)])
 def test_random_inputs_against_the_oracle(path, seed, capsys):
     tool = _tool()
-    args = argparse.Namespace(path=path, seconds=4.0, seed=seed)
+    args = argparse.Namespace(path=path, seconds=4.0, seed=seed, max_log2=11.7)
     try:
         {"brute": tool.run_brute, "batch": tool.run_batch, "cascade": tool.run_cascade, "geometry": tool.run_geometry}[path](args)
     except SystemExit as e:     # the tool's way of reporting a difference
