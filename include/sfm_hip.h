@@ -338,7 +338,9 @@ int sfm_hip_cascade_image_order(const int64_t* pair_ids, int32_t n_pairs, int64_
 /* Everything CascadeHashMatcher::Match does before its pair loop (cascade_hash_matcher.cc:122-171)
  * for the uploaded images a pair list names: reference projection, column sums of every image,
  * the mean vector (shares added in image_order, divided by the total descriptor count) and the
- * hashes of every image.  out_mean128 (128 floats, may be NULL) receives the mean.  Blocking. */
+ * hashes of every image.  out_mean128 (128 floats, may be NULL) receives the mean.  Blocking.
+ * The reference projection is drawn and installed by the context's first call and kept; a call
+ * that follows sfm_hip_cascade_set_projection installs it again. */
 int sfm_hip_cascade_prepare(sfm_hip_ctx* ctx, const int64_t* pair_ids, int32_t n_pairs, float* out_mean128);
 
 /* Statistics of the cascade path; timing as sfm_hip_set_profiling describes. */
