@@ -145,6 +145,14 @@ __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
   return d;
 }
 
+// Median of three as one instruction where the compiler, seeing what follows, would take the
+// expression apart into four.
+__device__ __forceinline__ uint32_t med3u_one(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 // Insert x into the ascending triple (a <= b <= c), dropping the largest of the four.
 __device__ __forceinline__ void insert3(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t x) {
   c = med3u(b, c, x);
@@ -456,31 +464,33 @@ __device__ __forceinline__ void pair_steps(std::integer_sequence<int, S...>, f32
    ...);
 }
 
-// Fold one finished accumulator tile into the lane's row lists and column list: five vector
-// instructions per element (the key, two for either list).
+// Two keys into a sorted two-entry list (a <= b) at once: the smallest of {a, x, y}, and the second
+// smallest of {a, b, x, y}, which is min(b, median of {a, x, y}) because b is not below a.  Three
+// instructions where two single insertions take four.
+__device__ __forceinline__ void insert_pair(uint32_t& a, uint32_t& b, uint32_t x, uint32_t y) {
+  const uint32_t mid = med3u_one(a, x, y);
+  a = min3u(a, x, y);
+  b = umin32(b, mid);
+}
+
+// Fold one finished accumulator tile into the lane's row lists and column list: four vector
+// instructions per element (the key, three for two keys into either list).
 // kx = the index bits of the tile pair's keys (column-tile number << KEY_TILE_SHIFT, + RT * 32 + reg),
 // one scalar per element, built beside the matrix instructions; RT = which of the wave's two row tiles.
-// The column list takes its keys three at a time: the two smallest of three are one v_min3 and one
-// v_med3, and merging a sorted pair into a sorted pair takes three more -- five instructions where
-// three single insertions take six.
-template <int RT>
+// A row's keys arrive one per column tile, so the row lists take them two column tiles at a time:
+// WHEN = 0 keeps this tile's keys in `held`, WHEN = 1 inserts them together with this tile's.
+template <int RT, int WHEN>
 __device__ __forceinline__ void tile_fold(const f32x16& acc, const KeyIndex& kx, uint32_t vmask, LaneLists& L, uint32_t& cl0,
-                                          uint32_t& cl1) {
+                                          uint32_t& cl1, uint32_t (&held)[16]) {
   uint32_t key[16];
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
     key[reg] = (__float_as_uint(acc[reg]) & vmask) | kx.c[RT * 16 + reg];
-    insert2(L.r0[reg], L.r1[reg], key[reg]);
+    if constexpr (WHEN == 0) held[reg] = key[reg];
+    else insert_pair(L.r0[reg], L.r1[reg], held[reg], key[reg]);
   }
 #pragma unroll
-  for (int g = 0; g < 15; g += 3) {
-    const uint32_t m = min3u(key[g], key[g + 1], key[g + 2]);
-    const uint32_t s = med3u(key[g], key[g + 1], key[g + 2]);
-    const uint32_t t = umax32(cl0, m);
-    cl0 = umin32(cl0, m);
-    cl1 = min3u(t, cl1, s);   // second smallest of {cl0 <= cl1, m <= s}: min(max(cl0, m), min(cl1, s))
-  }
-  insert2(cl0, cl1, key[15]);
+  for (int g = 0; g < 16; g += 2) insert_pair(cl0, cl1, key[g], key[g + 1]);
 }
 
 // One column tile (32 columns) against the wave's 64 rows: 2 x 65 MFMAs, then the vector
@@ -496,7 +506,8 @@ __device__ __forceinline__ void tile_fold(const f32x16& acc, const KeyIndex& kx,
 template <int ENGINE, int CT>
 __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
                                           f32x4 (&b)[NFRAG], const uint32_t (&X)[8], uint32_t tile6, uint32_t vmask,
-                                          LaneLists& L0, LaneLists& L1, uint32_t lowc, int h, uint32_t* cb, const StageFeed& feed,
+                                          LaneLists& L0, LaneLists& L1, uint32_t (&held0)[16], uint32_t (&held1)[16], uint32_t lowc,
+                                          int h, uint32_t* cb, const StageFeed& feed,
                                           const uint32_t (&yvoff)[8] SFM_FOLD_CYCLES_PARAM) {
   constexpr int TOFF = CT * 32 * DIM * 4;
 #ifdef SFM_K1_STAMPS
@@ -525,8 +536,8 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
   g_fold_cycles += (tf0 - tm0) << 32;   // high half: the matrix section of the tile pair
   __builtin_amdgcn_sched_barrier(0);
 #endif
-  tile_fold<0>(acc0, kx, vmask, L0, cl0, cl1);
-  tile_fold<1>(acc1, kx, vmask, L1, cl0, cl1);
+  tile_fold<0, CT & 1>(acc0, kx, vmask, L0, cl0, cl1, held0);
+  tile_fold<1, CT & 1>(acc1, kx, vmask, L1, cl0, cl1, held1);
 #ifdef SFM_K1_STAMPS
   anchor16(L0.r0); anchor16(L0.r1);
   anchor16(L1.r0); anchor16(L1.r1);
@@ -901,10 +912,11 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
       stamp_head += __builtin_amdgcn_s_memtime() - th0;
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0 * T1, vmask, L0, L1, lowc, h, cb + 0 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
-      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1 * T1, vmask, L0, L1, lowc, h, cb + 1 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
-      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2 * T1, vmask, L0, L1, lowc, h, cb + 2 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
-      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3 * T1, vmask, L0, L1, lowc, h, cb + 3 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      uint32_t held0[16], held1[16];   // the keys of column tiles 0 and 2 until those of 1 and 3 join them in the row lists
+      tile_pair<ENGINE, 0>(a0, a1, an0, an1, bn[0], b, X, tv + 0 * T1, vmask, L0, L1, held0, held1, lowc, h, cb + 0 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 1>(a0, a1, an0, an1, bn[1], b, X, tv + 1 * T1, vmask, L0, L1, held0, held1, lowc, h, cb + 1 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 2>(a0, a1, an0, an1, bn[2], b, X, tv + 2 * T1, vmask, L0, L1, held0, held1, lowc, h, cb + 2 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
+      tile_pair<ENGINE, 3>(a0, a1, an0, an1, bn[3], b, X, tv + 3 * T1, vmask, L0, L1, held0, held1, lowc, h, cb + 3 * 128, feed, yvoff SFM_FOLD_CYCLES_ARG);
     } else {
       constexpr auto STEPS = std::make_integer_sequence<int, 16>{};
       f32x16 e0, e1, o0, o1;   // accumulators of the even and of the odd column tiles
