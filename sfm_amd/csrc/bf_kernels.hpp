@@ -568,31 +568,39 @@ __device__ __forceinline__ void tile_pair(const f32x4 (&a0)[16], const f32x4 (&a
 // ---------------------------------------------------------------------------
 struct FoldState {
   uint32_t cl0, cl1;   // the column list being built for the tile that is folded
+  uint32_t prev;       // the key of the element before this one, when that was an even one (keys go in two at a time)
 };
 
 // Element E of a finished tile pair: E < 16 is register E of the first row tile's accumulator.
-template <int E>
+// Keys go into the lists two at a time (insert_pair): the column list takes elements 2k and 2k + 1
+// together; a row's keys arrive one per column tile, so WHEN = 0 (column tiles 0 and 2 of a stage)
+// keeps the key in held[E] and WHEN = 1 (tiles 1 and 3) inserts it together with this one.
+template <int E, int WHEN>
 __device__ __forceinline__ void fold_elem(const f32x16& p0, const f32x16& p1, uint32_t tile6, uint32_t vmask, LaneLists& L0,
-                                          LaneLists& L1, FoldState& f) {
+                                          LaneLists& L1, FoldState& f, uint32_t (&held)[32]) {
   constexpr int RT = E >> 4, REG = E & 15;
   const uint32_t gb = __float_as_uint(RT == 0 ? p0[REG] : p1[REG]);
   LaneLists& L = RT == 0 ? L0 : L1;
   const uint32_t key = (gb & vmask) | (tile6 + (uint32_t)(RT * 32 + REG));
-  insert2(L.r0[REG], L.r1[REG], key);
-  insert2(f.cl0, f.cl1, key);
+  if constexpr (WHEN == 0) held[E] = key;
+  else insert_pair(L.r0[REG], L.r1[REG], held[E], key);
+  if constexpr ((E & 1) == 0) f.prev = key;
+  else insert_pair(f.cl0, f.cl1, f.prev, key);
 }
-template <int... E>
+template <int WHEN, int... E>
 __device__ __forceinline__ void fold_elems(std::integer_sequence<int, E...>, const f32x16& p0, const f32x16& p1,
-                                           uint32_t tile6, uint32_t vmask, LaneLists& L0, LaneLists& L1, FoldState& f) {
-  (fold_elem<E>(p0, p1, tile6, vmask, L0, L1, f), ...);
+                                           uint32_t tile6, uint32_t vmask, LaneLists& L0, LaneLists& L1, FoldState& f,
+                                           uint32_t (&held)[32]) {
+  (fold_elem<E, WHEN>(p0, p1, tile6, vmask, L0, L1, f, held), ...);
 }
 
 template <int CT, int S, bool FOLD, bool HAS_NEXT, int PIECE>
 __device__ __forceinline__ void pipe_step(f32x16& acc0, f32x16& acc1, const f32x4 (&a0)[16], const f32x4 (&a1)[16],
                                           f32x4 (&b)[NFRAG], const uint32_t (&X)[8], const StageFeed& feed,
                                           const uint32_t (&yvoff)[8], const f32x16& p0, const f32x16& p1, uint32_t tvp,
-                                          uint32_t vmask, LaneLists& L0, LaneLists& L1, FoldState& f) {
+                                          uint32_t vmask, LaneLists& L0, LaneLists& L1, FoldState& f, uint32_t (&held)[32]) {
   constexpr int TOFF = CT * 32 * DIM * 4;
+  constexpr int WHEN = (CT + 1) & 1;   // the tile that is folded is CT - 1
   if constexpr (S + 2 < 16) {
     lds_read16<TOFF + ((S + 2) >> 3) * 256>(b[(16 * CT + S + 2) % NFRAG], X[(S + 2) & 7]);
     lds_wait<2>();
@@ -607,16 +615,16 @@ __device__ __forceinline__ void pipe_step(f32x16& acc0, f32x16& acc1, const f32x
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S]), frag, acc1, 0, 0, 0);
     if constexpr (FOLD) {
-      fold_elem<4 * (S / 2)>(p0, p1, tvp, vmask, L0, L1, f);
-      fold_elem<4 * (S / 2) + 1>(p0, p1, tvp, vmask, L0, L1, f);
+      fold_elem<4 * (S / 2), WHEN>(p0, p1, tvp, vmask, L0, L1, f, held);
+      fold_elem<4 * (S / 2) + 1, WHEN>(p0, p1, tvp, vmask, L0, L1, f, held);
     }
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S + 1]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S + 1]), frag, acc1, 0, 0, 0);
-    if constexpr (FOLD) fold_elem<4 * (S / 2) + 2>(p0, p1, tvp, vmask, L0, L1, f);
+    if constexpr (FOLD) fold_elem<4 * (S / 2) + 2, WHEN>(p0, p1, tvp, vmask, L0, L1, f, held);
   } else {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[S - 1]), frag, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[S - 1]), frag, acc1, 0, 0, 0);
-    if constexpr (FOLD) fold_elem<4 * (S / 2) + 3>(p0, p1, tvp, vmask, L0, L1, f);
+    if constexpr (FOLD) fold_elem<4 * (S / 2) + 3, WHEN>(p0, p1, tvp, vmask, L0, L1, f, held);
   }
 #ifndef SFM_ABLATE_GLDS
   if constexpr (PIECE >= 0) stage_load_piece<PIECE>(feed.src, feed.ldsbuf, feed.w, yvoff, feed.sbase);
@@ -631,7 +639,8 @@ __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x
                                           const f32x4 (&a0)[16], const f32x4 (&a1)[16], float an0, float an1, float bn,
                                           f32x4 (&b)[NFRAG], const uint32_t (&X)[8], const StageFeed& feed,
                                           const uint32_t (&yvoff)[8], const f32x16& p0, const f32x16& p1, uint32_t tvp,
-                                          uint32_t vmask, LaneLists& L0, LaneLists& L1, uint32_t lowc, uint32_t* cbp) {
+                                          uint32_t vmask, LaneLists& L0, LaneLists& L1, uint32_t (&held)[32], uint32_t lowc,
+                                          uint32_t* cbp) {
   if constexpr (CT == 0) {
     lds_read16<0>(b[0], X[0]);
     lds_read16<0>(b[1], X[1]);
@@ -641,9 +650,9 @@ __device__ __forceinline__ void pipe_tile(std::integer_sequence<int, S...>, f32x
   for (int i = 0; i < 16; i++) zero[i] = 0.0f;
   acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an0, bn, zero, 0, 0, 0);
   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an1, bn, zero, 0, 0, 0);
-  FoldState f{SENT, SENT};
+  FoldState f{SENT, SENT, SENT};
   (pipe_step<CT, S, FOLD, (CT < 3), SFM_PIECE_AT(CT, S)>(acc0, acc1, a0, a1, b, X, feed, yvoff, p0, p1, tvp,
-                                                                        vmask, L0, L1, f),
+                                                                        vmask, L0, L1, f, held),
    ...);
   if constexpr (FOLD) {
     // all thirty-two elements went in beside the matrix instructions: the tile's column lists are complete
@@ -920,13 +929,14 @@ __global__ __launch_bounds__(256, 1) void k_distance_topk(const PairDev* __restr
     } else {
       constexpr auto STEPS = std::make_integer_sequence<int, 16>{};
       f32x16 e0, e1, o0, o1;   // accumulators of the even and of the odd column tiles
-      pipe_tile<0, false>(STEPS, e0, e1, a0, a1, an0, an1, bn[0], b, X, feed, yvoff, o0, o1, tv, vmask, L0, L1, lowc, cb);
-      pipe_tile<1, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[1], b, X, feed, yvoff, e0, e1, tv + 0 * T1, vmask, L0, L1, lowc, cb + 0 * 128);
-      pipe_tile<2, true>(STEPS, e0, e1, a0, a1, an0, an1, bn[2], b, X, feed, yvoff, o0, o1, tv + 1 * T1, vmask, L0, L1, lowc, cb + 1 * 128);
-      pipe_tile<3, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[3], b, X, feed, yvoff, e0, e1, tv + 2 * T1, vmask, L0, L1, lowc, cb + 2 * 128);
+      uint32_t held[32];   // the keys of column tiles 0 and 2 until those of 1 and 3 join them in the row lists
+      pipe_tile<0, false>(STEPS, e0, e1, a0, a1, an0, an1, bn[0], b, X, feed, yvoff, o0, o1, tv, vmask, L0, L1, held, lowc, cb);
+      pipe_tile<1, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[1], b, X, feed, yvoff, e0, e1, tv + 0 * T1, vmask, L0, L1, held, lowc, cb + 0 * 128);
+      pipe_tile<2, true>(STEPS, e0, e1, a0, a1, an0, an1, bn[2], b, X, feed, yvoff, o0, o1, tv + 1 * T1, vmask, L0, L1, held, lowc, cb + 1 * 128);
+      pipe_tile<3, true>(STEPS, o0, o1, a0, a1, an0, an1, bn[3], b, X, feed, yvoff, e0, e1, tv + 2 * T1, vmask, L0, L1, held, lowc, cb + 2 * 128);
       // the stage's last tile has no matrix work left to hide behind
-      FoldState f{SENT, SENT};
-      fold_elems(std::make_integer_sequence<int, 32>{}, o0, o1, tv + 3 * T1, vmask, L0, L1, f);
+      FoldState f{SENT, SENT, SENT};
+      fold_elems<1>(std::make_integer_sequence<int, 32>{}, o0, o1, tv + 3 * T1, vmask, L0, L1, f, held);
       cb[3 * 128 + 0] = (f.cl0 & COL_PARK_MASK) | lowc;
       cb[3 * 128 + 64] = (f.cl1 & COL_PARK_MASK) | lowc;
       anchor16(L0.r0); anchor16(L0.r1);
