@@ -202,10 +202,12 @@ __device__ __forceinline__ double epipolar_line_error(double x, double y, double
 }
 
 // `epipolar_line_error(...) > 3.84` (ransac.hpp:118), decided exactly but usually without the two
-// divisions (about fifteen instructions each): with hardware reciprocals the error is known to a
-// relative 1e-3 at the very worst, which settles every match whose error is not within that of
-// 3.84; the others, and anything out of the ordinary range (a NaN fails every comparison and lands
-// there too), take the exact route.
+// divisions (about fifteen instructions each): with num^2 = nn and the two squared line norms s1, s2
+// the error is nn (1/s1 + 1/s2), and in real numbers that exceeds 3.84 exactly when
+// nn (s1 + s2) > 3.84 s1 s2.  Both sides are known to a few units in the last place, so unless they
+// agree to one part in 10^9 the comparison says what the reference's own arithmetic says; the
+// others, and anything out of the ordinary range (a NaN fails every comparison and lands there
+// too), take the exact route.
 __device__ __forceinline__ bool epipolar_error_exceeds(double x, double y, double xp, double yp, const double (&F)[9]) {
 #pragma clang fp contract(off)
   const double lx = (F[0] * x + F[1] * y) + F[2];
@@ -215,10 +217,10 @@ __device__ __forceinline__ bool epipolar_error_exceeds(double x, double y, doubl
   const double rz = (F[2] * xp + F[5] * yp) + F[8];
   const double num = (rx * x + ry * y) + rz;
   const double s1 = lx * lx + ly * ly, s2 = rx * rx + ry * ry, nn = num * num;
-  const double approx = nn * (__builtin_amdgcn_rcp(s1) + __builtin_amdgcn_rcp(s2));
-  const bool tame = fmin(s1, s2) > 1e-200 && fmax(s1, s2) < 1e200;
-  if (tame && approx > 3.84 * 1.001) return true;
-  if (tame && approx < 3.84 * 0.999) return false;
+  const double lhs = nn * (s1 + s2), rhs = (3.84 * s1) * s2;
+  const bool tame = fmin(s1, s2) > 1e-100 && fmax(s1, s2) < 1e100;   // the products neither overflow nor vanish
+  if (tame && lhs > rhs * (1.0 + 1e-9)) return true;
+  if (tame && lhs < rhs * (1.0 - 1e-9)) return false;
   const double deno = 1.0 / s1 + 1.0 / s2;
   return nn * deno > 3.84;
 }
