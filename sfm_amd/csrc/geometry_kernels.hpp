@@ -380,6 +380,7 @@ __global__ __launch_bounds__(ROUNDS_PER_LAUNCH) void k_geo_count(const GeoPair* 
     }
     __syncthreads();
     if (live) {
+#pragma unroll 4
       for (int t = 0; t < m; t++) {
         const double2 a = tile_l[t], b = tile_r[t];
         count += epipolar_error_exceeds(a.x, a.y, b.x, b.y, F) ? 0u : 1u;
