@@ -297,6 +297,32 @@ def replication_check(m, rank, world, device, barrier, n_images=64):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def with_deadline(fn, seconds, what, device=None):
+    """An optional multi-rank leg, in a thread of its own: a leg that has not returned after `seconds`
+    (a rank stuck in a collective that another rank never entered) is given up, so that the line still
+    goes out.  Returns (result, gave_up); after gave_up the caller starts nothing more on the GPU --
+    the thread may still be inside the library -- and ends the process with os._exit once the line is
+    printed."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            if device is not None and device.type == "cuda":
+                import torch
+                torch.cuda.set_device(device)      # the current device is a per-thread setting
+            box["result"] = fn()
+        except Exception as e:   # a report, not a gate
+            box["result"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return {"error": "%s did not finish within %d s on rank %s: given up" % (what, seconds, os.environ.get("RANK", "0"))}, True
+    return box.get("result"), False
+
+
 SET_SEED = 4242
 PAIRS_PER_CALL = 64
 
@@ -640,6 +666,9 @@ def main():
                     help="before the W warm-up steps, run the step for this long: the GPU needs ~25 ms of "
                          "load to reach its working clocks (the first 50 steps take 175-195 us each, "
                          "steps after the 150th 150 us), whatever W is")
+    ap.add_argument("--extra-leg-seconds", type=float, default=150.0,
+                    help="N > 1: the replication check is given up after this many seconds, the whole-job leg after "
+                         "twice as many (a rank stuck in a collective must not cost the line)")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not bracket the distance kernel with HIP events in the timed region")
     args = ap.parse_args()
@@ -814,6 +843,7 @@ def main():
 
     flop_per_pair = 2.0 * N_FEATURES * N_FEATURES * 128
     line = None
+    gave_up = False   # an optional multi-rank leg ran out of time (with_deadline)
     if dist_on:
         # secondary: each rank's single-pair rate (BASELINE.json configs[1]) on the first pair of its shard
         one = job.pairs[job.mine[:1]]
@@ -831,8 +861,16 @@ def main():
         ordinals = torch.zeros(world, dtype=torch.float64, device=coll_device)
         ordinals[rank] = device.index
         dist.all_reduce(ordinals)
-        replication = None if args.no_replication_check else replication_check(m, rank, world, coll_device, barrier)
-        whole = None if args.no_whole_job else whole_job_leg(m, job, barrier, max_over_ranks, coll_device, args.engine)
+        # The two legs below are extras with collectives in them; neither may cost the line above them.
+        replication, whole = None, None
+        if not args.no_replication_check:
+            replication, gave_up = with_deadline(lambda: replication_check(m, rank, world, coll_device, barrier),
+                                                 args.extra_leg_seconds, "the replication check", device)
+        if not args.no_whole_job and not gave_up:
+            whole, gave_up = with_deadline(lambda: whole_job_leg(m, job, barrier, max_over_ranks, coll_device, args.engine),
+                                           2 * args.extra_leg_seconds, "the whole-job leg", device)
+        elif not args.no_whole_job:
+            whole = {"error": "not started: an earlier leg was given up"}
         if rank == 0:
             value = args.steps * per_step * world / elapsed
             cnt = out[0]
@@ -960,6 +998,11 @@ def main():
                 line["geometry"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if line is not None:
         print(json.dumps(line), flush=True)
+    if gave_up:
+        # a thread of this process is still inside a collective or the library: no orderly way out
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
     m.close()
     if dist_on:
