@@ -206,8 +206,8 @@ __device__ __forceinline__ double epipolar_line_error(double x, double y, double
 // the error is nn (1/s1 + 1/s2), and in real numbers that exceeds 3.84 exactly when
 // nn (s1 + s2) > 3.84 s1 s2.  Both sides are known to a few units in the last place, so unless they
 // agree to one part in 10^9 the comparison says what the reference's own arithmetic says; the
-// others, and anything out of the ordinary range (a NaN fails every comparison and lands there
-// too), take the exact route.
+// others, and anything out of the ordinary (a NaN fails every comparison and lands there too), take
+// the exact route.
 __device__ __forceinline__ bool epipolar_error_exceeds(double x, double y, double xp, double yp, const double (&F)[9]) {
 #pragma clang fp contract(off)
   const double lx = (F[0] * x + F[1] * y) + F[2];
@@ -218,7 +218,9 @@ __device__ __forceinline__ bool epipolar_error_exceeds(double x, double y, doubl
   const double num = (rx * x + ry * y) + rz;
   const double s1 = lx * lx + ly * ly, s2 = rx * rx + ry * ry, nn = num * num;
   const double lhs = nn * (s1 + s2), rhs = (3.84 * s1) * s2;
-  const bool tame = fmin(s1, s2) > 1e-100 && fmax(s1, s2) < 1e100;   // the products neither overflow nor vanish
+  // the right side a normal number: its product neither overflowed nor lost bits to underflow (the left
+  // side may do either: it then compares as the infinite or vanishing quantity it stands for)
+  const bool tame = __builtin_amdgcn_class(rhs, 0x100);   // positive normal
   if (tame && lhs > rhs * (1.0 + 1e-9)) return true;
   if (tame && lhs < rhs * (1.0 - 1e-9)) return false;
   const double deno = 1.0 / s1 + 1.0 / s2;
