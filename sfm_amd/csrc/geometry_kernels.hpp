@@ -230,12 +230,15 @@ __device__ __forceinline__ bool epipolar_error_exceeds(double x, double y, doubl
 // ---------------------------------------------------------------------------------------------
 // 256 rounds (or a few runs of 256) of every unfinished pair, in two kernels because they want opposite things from the
 // register file: the fit keeps two matrices in registers and runs one wavefront per SIMD, the
-// count needs few registers and hides its divisions behind eight.
-//   k_geo_fit    thread = one round: sample, fit.  grid: (4 * runs, pairs), 64 threads.
+// count needs few registers and hides its divisions behind eight -- and so does the sampler, whose
+// walk over the matches is a chain of dependent integer instructions that a wavefront alone on its
+// SIMD issues at two thirds of the rate.
+//   k_geo_sample thread = one round: the eight matches it is fitted to.  grid: (4 * runs, pairs), 64 threads.
+//   k_geo_fit    thread = one round: the fit.  grid: (4 * runs, pairs), 64 threads.
 //   k_geo_count  thread = one round, workgroup = the 256 rounds of a pair: the matches pass through
 //                LDS in tiles, every thread measures each of them against its model.  grid: (pairs, runs).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HYP_THREADS) void k_geo_fit(const GeoPair* __restrict__ pairs, uint32_t first_round) {
+__global__ __launch_bounds__(HYP_THREADS) void k_geo_sample(const GeoPair* __restrict__ pairs, uint32_t first_round) {
 #pragma clang fp contract(off)
   const GeoPair P = pairs[blockIdx.y];
   const GeoState* st = P.state;
@@ -333,6 +336,20 @@ __global__ __launch_bounds__(HYP_THREADS) void k_geo_fit(const GeoPair* __restri
   }
 #endif
   if (!active) return;
+#pragma unroll
+  for (int k = 0; k < SAMPLE; k++) P.hyp_idx[(size_t)slot * SAMPLE + k] = idx[k];
+}
+
+__global__ __launch_bounds__(HYP_THREADS) void k_geo_fit(const GeoPair* __restrict__ pairs, uint32_t first_round) {
+#pragma clang fp contract(off)
+  const GeoPair P = pairs[blockIdx.y];
+  const GeoState* st = P.state;
+  if (st->done) return;
+  const uint32_t slot = blockIdx.x * HYP_THREADS + threadIdx.x;
+  if (first_round + slot >= st->rounds_limit) return;   // as k_geo_sample decided
+  int idx[SAMPLE];
+#pragma unroll
+  for (int k = 0; k < SAMPLE; k++) idx[k] = P.hyp_idx[(size_t)slot * SAMPLE + k];
   double px[SAMPLE], py[SAMPLE], qx[SAMPLE], qy[SAMPLE];
 #pragma unroll
   for (int k = 0; k < SAMPLE; k++) {
@@ -349,8 +366,6 @@ __global__ __launch_bounds__(HYP_THREADS) void k_geo_fit(const GeoPair* __restri
 #endif
 #pragma unroll
   for (int k = 0; k < 9; k++) P.hyp_F[(size_t)slot * 9 + k] = F[k];
-#pragma unroll
-  for (int k = 0; k < SAMPLE; k++) P.hyp_idx[(size_t)slot * SAMPLE + k] = idx[k];
 }
 
 constexpr int COUNT_TILE = 256;

@@ -189,8 +189,10 @@ int sfm_hip_geometry_verify_pairs(sfm_hip_ctx* ctx, int32_t n_pairs, const int64
     chunks_queued += chunks;
     int mrc;
     if ((mrc = mark())) return mrc;
-    hipLaunchKernelGGL(k_geo_fit, dim3((unsigned)(chunks * (ROUNDS_PER_LAUNCH / HYP_THREADS)), (unsigned)n_live), dim3(HYP_THREADS), 0, st,
-                       dp, first);
+    const dim3 per_round((unsigned)(chunks * (ROUNDS_PER_LAUNCH / HYP_THREADS)), (unsigned)n_live);
+    hipLaunchKernelGGL(k_geo_sample, per_round, dim3(HYP_THREADS), 0, st, dp, first);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_geo_fit, per_round, dim3(HYP_THREADS), 0, st, dp, first);
     HIP_TRY(ctx, hipGetLastError());
     if ((mrc = mark())) return mrc;
     hipLaunchKernelGGL(k_geo_count, dim3((unsigned)n_live, (unsigned)chunks), dim3(ROUNDS_PER_LAUNCH), 0, st, dp, first);
