@@ -383,7 +383,7 @@ typedef struct {
                               rounds the pairs report, since a launch works on 256 or more rounds of a pair at once
                               and the rounds behind the pair's stopping point are discarded */
   uint64_t match_rounds;   /* (match, round) pairs the count measured: sum over those rounds of the pair's matches */
-  double fit_ms;           /* summed duration of the timed launches' k_geo_fit */
+  double fit_ms;           /* summed duration of the timed launches' k_geo_sample + k_geo_fit (samples, then models) */
   double count_ms;         /* ... and of their k_geo_count */
 } sfm_hip_geometry_stats;
 int sfm_hip_geometry_get_stats(sfm_hip_ctx* ctx, sfm_hip_geometry_stats* out);
